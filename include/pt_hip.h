@@ -1,0 +1,179 @@
+/*
+ * pt_hip.h -- C ABI of libpt_hip.so: the MI355X (gfx950) replacement for the Vulkan
+ * ray-tracing entry points the reference's hot path goes through.
+ *
+ * The reference has no FFI for this path: its C++ classes call Vulkan directly.  Each entry
+ * point below names the Vulkan call site(s) (reference file:line) it replaces.  All functions
+ * return 0 on success and a non-zero PtStatus otherwise; pt_last_error() returns a thread-local
+ * description (the reference logs and abort()s instead, source/vk_common.cpp:5-15 -- the C++
+ * wrappers may do the same on a non-zero status).
+ *
+ * Conventions: plain pointers and sizes only; "_dev" arguments are device pointers valid on the
+ * context's GPU; everything else is host memory.  One host thread per context; calls on a context
+ * are asynchronous on its HIP stream unless stated, pt_sync() waits for them.
+ */
+#ifndef PT_HIP_H
+#define PT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum PtStatus {
+    PT_OK = 0,
+    PT_ERROR_INVALID_ARGUMENT = 1,
+    PT_ERROR_HIP = 2,
+    PT_ERROR_OUT_OF_MEMORY = 3,
+    PT_ERROR_LIMIT = 4
+} PtStatus;
+
+typedef struct PtContext PtContext;
+typedef struct PtBlas PtBlas;
+typedef struct PtTlas PtTlas;
+
+/* ---- device-visible table layouts (shaders/bindless.glsl:3-51,
+ *      include/resources/gpu_resources.hpp:157-205) */
+typedef struct PtMaterial {              /* std140, 96 bytes */
+    float    albedoFactor[4];
+    float    metallicFactor, roughnessFactor, normalScale, occlusionStrength;
+    float    emissiveFactor[3];
+    int32_t  useEmissiveMap;
+    int32_t  useAlbedoMap, useMRMap, useNormalMap, useOcclusionMap;
+    uint32_t albedoMapIndex, mrMapIndex, normalMapIndex, occlusionMapIndex;
+    uint32_t emissiveMapIndex;
+    uint32_t pad[3];
+} PtMaterial;
+
+typedef struct PtGeometryNode {          /* 32 bytes */
+    uint64_t vertexBufferDeviceAddress;  /* interleaved 32-byte vertices {pos, normal, uv} */
+    uint64_t indexBufferDeviceAddress;   /* u32 indices, already offset to the mesh's first index */
+    uint32_t materialIndex;
+    uint32_t pad[3];
+} PtGeometryNode;
+
+typedef struct PtBLASInstance { uint32_t firstGeometryIndex; } PtBLASInstance;
+
+/* VkAccelerationStructureInstanceKHR (64 bytes) as filled by
+ * source/top_level_acceleration_structure.cpp:25-36; accelerationStructureReference holds the
+ * PtBlas* returned by pt_blas_build. */
+typedef struct PtInstance {
+    float    transform[12];              /* row-major 3x4 object->world (source/vk_common.cpp:205-212) */
+    uint32_t instanceCustomIndexAndMask; /* [23:0] custom index, [31:24] mask */
+    uint32_t sbtOffsetAndFlags;          /* [23:0] SBT record offset, [31:24] VkGeometryInstanceFlags */
+    uint64_t accelerationStructureReference;
+} PtInstance;
+
+typedef struct PtTextureDesc { uint64_t rgba8_dev; uint32_t width, height; } PtTextureDesc;
+
+typedef struct PtHit { uint32_t instance, primitive; float u, v; } PtHit;   /* instance = 0xFFFFFFFF: miss */
+
+/* 64-byte BVH node: both child boxes and both child references.
+ * child >= 0: inner node index; child < 0: leaf, ~child = first << 3 | (count - 1), positions in
+ * the sorted primitive order; INT32_MIN: empty slot. */
+typedef struct PtBvhNode {
+    float   lo0[3], hi0[3], lo1[3], hi1[3];
+    int32_t c0, c1;
+    uint32_t aux0, aux1;
+} PtBvhNode;
+
+typedef struct PtAsInfo {
+    uint32_t node_count, prim_count;
+    float    root_lo[3], root_hi[3];
+    float    delta;                      /* box padding of this structure */
+    float    build_ms;                   /* device time of the build */
+} PtAsInfo;
+
+#define PT_MAX_DEPTH 64
+typedef struct PtTraceStats {
+    uint64_t rays_per_depth[PT_MAX_DEPTH]; /* rays traced at each bounce since pt_trace_stats_reset */
+    uint64_t rays, paths;
+} PtTraceStats;
+
+enum { PT_SEED_SAMPLE_INDEX = 0,  /* seed = TEA(pixel, frame * spp + i): deterministic */
+       PT_SEED_CLOCK = 1 };       /* seed = TEA(pixel, clock): what ray_gen.rgen:40 does */
+enum { PT_ACCUM_SUM_F32 = 0,      /* float4 per pixel: rgb += frame result, a += 1 */
+       PT_ACCUM_MEAN_F32 = 1,     /* float4 per pixel: literal mix() of ray_gen.rgen:77-87 */
+       PT_ACCUM_MEAN_UNORM8 = 2 };/* 4 x u8 per pixel: literal mix() on an 8-bit UNORM image */
+
+const char* pt_last_error(void);
+
+/* Replaces VulkanContext device/queue selection (source/vulkan_context.cpp:99-113): binds a GPU
+ * and creates a stream.  hip_stream may be NULL (a new stream is created) or an existing
+ * hipStream_t to enqueue on (for example PyTorch's current stream). */
+int pt_ctx_create(int device_id, void* hip_stream, PtContext** out);
+int pt_ctx_destroy(PtContext* ctx);
+int pt_sync(PtContext* ctx);
+
+/* Replaces the staging-buffer uploads of source/model_loader.cpp:307-357 and
+ * source/resources/gpu_resources.cpp:207-271: hipMalloc + copy.  Synchronous. */
+int pt_buffer_upload(PtContext* ctx, const void* host, size_t bytes, void** dev_out);
+int pt_buffer_download(PtContext* ctx, const void* dev, size_t bytes, void* host_out);
+int pt_buffer_free(PtContext* ctx, void* dev);
+
+/* Replaces getAccelerationStructureBuildSizesKHR + createAccelerationStructureKHR +
+ * cmdBuildAccelerationStructuresKHR for one triangle geometry
+ * (source/bottom_level_acceleration_structure.cpp:34-78, inputs source/renderer.cpp:417-455):
+ * R32G32B32 positions at vertex_stride, u32 indices, opaque, build mode only.
+ * max_leaf = 0 selects the default (4).  Blocks until built, like the reference's
+ * SingleTimeCommands::SubmitAndWait.  The BLAS keeps references to the caller's buffers. */
+int pt_blas_build(PtContext* ctx, const void* vertices_dev, uint32_t vertex_stride, uint32_t max_vertex,
+                  const uint32_t* indices_dev, uint32_t prim_count, uint32_t max_leaf, PtBlas** out);
+int pt_blas_destroy(PtBlas* blas);   /* destroyAccelerationStructureKHR, bottom_level_...cpp:19 */
+int pt_blas_info(const PtBlas* blas, PtAsInfo* out);
+/* Copies the built structure to the host (any pointer may be NULL): nodes[node_count],
+ * leaf_prims[prim_count] (primitive ids in sorted order), sorted_keys[prim_count]. */
+int pt_blas_download(const PtBlas* blas, PtBvhNode* nodes, uint32_t* leaf_prims, uint64_t* sorted_keys);
+
+/* Replaces the TLAS build of source/top_level_acceleration_structure.cpp:19-113: n instance
+ * records in host memory.  Blocks until built. */
+int pt_tlas_build(PtContext* ctx, const PtInstance* instances, uint32_t n, PtTlas** out);
+int pt_tlas_destroy(PtTlas* tlas);   /* top_level_...cpp:16 */
+int pt_tlas_info(const PtTlas* tlas, PtAsInfo* out);
+int pt_tlas_download(const PtTlas* tlas, PtBvhNode* nodes, uint32_t* leaf_instances,
+                     float* instance_boxes /* n x 6 */, float* instance_w2o /* n x 12 */);
+
+/* Replaces BindlessResources::UpdateDescriptorSet (source/resources/bindless_resources.cpp:70-76,
+ * bindings 0-3 of set 0, :250-274): copies the four tables to the GPU.  Table sizes are capped at
+ * 1024 entries like the reference (include/resources/bindless_resources.hpp:65). */
+int pt_scene_set_tables(PtContext* ctx,
+                        const PtMaterial* materials, uint32_t n_materials,
+                        const PtGeometryNode* geometry_nodes, uint32_t n_geometry_nodes,
+                        const PtBLASInstance* blas_instances, uint32_t n_blas_instances,
+                        const PtTextureDesc* textures, uint32_t n_textures);
+
+/* traceRayEXT on caller-supplied rays (shaders/ray_gen.rgen:54-65 without the shaders): closest
+ * hit over the TLAS, opaque, no culling, tmin < t < tmax.  origins/dirs are n x 3 floats;
+ * t_dev may be NULL. */
+int pt_intersect(PtContext* ctx, const PtTlas* tlas, uint32_t n, const float* origins_dev, const float* dirs_dev,
+                 float tmin, float tmax, PtHit* hits_dev, float* t_dev);
+
+/* Replaces cmdTraceRaysKHR(width, height, 1) with the ray_gen / closest_hit / miss pipeline
+ * (source/renderer.cpp:109-122): one frame of samples_per_frame paths per pixel, at most
+ * max_depth rays per path, accumulated into accum_dev according to accum_mode.
+ * camera = CameraUniformData (include/renderer.hpp:31-35): viewInverse then projInverse,
+ * column-major.  frame is the push constant (include/renderer.hpp:37-40).
+ * The reference's literals are samples_per_frame 25, max_depth 10 (shaders/ray_gen.rgen:34,52). */
+int pt_trace(PtContext* ctx, const PtTlas* tlas, const float camera[32], uint32_t width, uint32_t height,
+             uint32_t frame, uint32_t samples_per_frame, uint32_t max_depth,
+             uint32_t seed_mode, uint32_t accum_mode, void* accum_dev);
+
+/* Per-pixel value of `result` (shaders/ray_gen.rgen:74) of the last pt_trace: width*height*3
+ * floats to host memory.  Synchronous; for tests. */
+int pt_trace_last_result(PtContext* ctx, float* result_host);
+int pt_trace_stats(PtContext* ctx, PtTraceStats* out);       /* synchronous */
+int pt_trace_stats_reset(PtContext* ctx);
+/* Upper bound on paths resident at once (default 1<<25); a frame is rendered in pixel chunks. */
+int pt_ctx_set_max_paths(PtContext* ctx, uint64_t max_paths);
+
+/* Replaces the render-target -> swapchain blit (source/renderer.cpp:124-133): float sum buffer
+ * -> mean -> clamp -> RGBA8 (bgra != 0: B8G8R8A8, the preferred swapchain format,
+ * source/swap_chain.cpp:122-133). */
+int pt_accum_resolve(PtContext* ctx, const float* accum_sum_dev, uint32_t n_pixels, uint8_t* rgba8_dev, int bgra);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,703 @@
+// pt_build.hip -- BLAS / TLAS builders for gfx950.
+//
+// Replaces the driver BVH builds behind
+//   source/bottom_level_acceleration_structure.cpp:74-77  (vkCmdBuildAccelerationStructuresKHR, BLAS)
+//   source/top_level_acceleration_structure.cpp:109-112   (same, TLAS)
+// with an LBVH: 63-bit Morton keys -> stable LSD radix sort -> Karras radix tree -> bottom-up
+// boxes + area-weighted SAH cost with leaf collapse -> compact 64-byte nodes that carry both
+// child boxes (one node fetch = four 16-byte loads per lane) and 48-byte triangle records in
+// leaf order.  Every step is a pure function of its input, so the structure does not depend on
+// scheduling; nothing here hands data between workgroups inside a launch except through
+// commutative integer atomics read by a later kernel.
+#include "pt_internal.h"
+#include <math.h>
+#include <string.h>
+#include <limits>
+
+namespace {
+
+constexpr int kBlock = 256;
+
+__device__ __forceinline__ uint32_t f2ord(float f)
+{
+    uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__host__ __device__ __forceinline__ float ord2f(uint32_t u)
+{
+    uint32_t b = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+#ifdef __HIP_DEVICE_COMPILE__
+    return __uint_as_float(b);
+#else
+    float f; memcpy(&f, &b, 4); return f;
+#endif
+}
+
+// ---------------------------------------------------------------- triangle boxes
+__global__ void k_blas_maxabs(const uint8_t* __restrict__ vertices, uint32_t stride, const uint32_t* __restrict__ indices,
+                              uint32_t n_prims, uint32_t* __restrict__ maxabs_bits)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    float m = 0.0f;
+    if (i < n_prims) {
+        for (int k = 0; k < 3; ++k) {
+            const float* p = (const float*)(vertices + (size_t)indices[3 * i + k] * stride);
+            m = fmaxf(m, fmaxf(fabsf(p[0]), fmaxf(fabsf(p[1]), fabsf(p[2]))));
+        }
+    }
+    // non-negative floats order like their bit patterns
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0) atomicMax(maxabs_bits, __float_as_uint(m));
+}
+
+__global__ void k_tri_boxes(const uint8_t* __restrict__ vertices, uint32_t stride, const uint32_t* __restrict__ indices,
+                            uint32_t n_prims, const uint32_t* __restrict__ maxabs_bits, float* __restrict__ boxes,
+                            uint32_t* __restrict__ root_ord /* 6: lo xyz (min), hi xyz (max) */)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_prims) return;
+    const float delta = __uint_as_float(*maxabs_bits) * 3.0517578125e-05f;
+    const float* a = (const float*)(vertices + (size_t)indices[3 * i + 0] * stride);
+    const float* b = (const float*)(vertices + (size_t)indices[3 * i + 1] * stride);
+    const float* c = (const float*)(vertices + (size_t)indices[3 * i + 2] * stride);
+    for (int k = 0; k < 3; ++k) {
+        float lo = fminf(fminf(a[k], b[k]), c[k]) - delta;
+        float hi = fmaxf(fmaxf(a[k], b[k]), c[k]) + delta;
+        boxes[6 * (size_t)i + k] = lo;
+        boxes[6 * (size_t)i + 3 + k] = hi;
+        atomicMin(&root_ord[k], f2ord(lo));
+        atomicMax(&root_ord[3 + k], f2ord(hi));
+    }
+}
+
+// ---------------------------------------------------------------- Morton keys
+__global__ void k_centroid_bounds(const float* __restrict__ boxes, uint32_t n, uint32_t* __restrict__ cb_ord)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    for (int k = 0; k < 3; ++k) {
+        float c = (boxes[6 * (size_t)i + k] + boxes[6 * (size_t)i + 3 + k]) * 0.5f;
+        atomicMin(&cb_ord[k], f2ord(c));
+        atomicMax(&cb_ord[3 + k], f2ord(c));
+    }
+}
+
+__device__ __forceinline__ uint64_t expand21(uint32_t v)
+{
+    uint64_t x = v & 0x1fffffu;
+    x = (x | x << 32) & 0x1f00000000ffffull;
+    x = (x | x << 16) & 0x1f0000ff0000ffull;
+    x = (x | x << 8) & 0x100f00f00f00f00full;
+    x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+    x = (x | x << 2) & 0x1249249249249249ull;
+    return x;
+}
+__device__ __forceinline__ uint32_t quantize21(float c, float cmin, float cmax)
+{
+    float ext = cmax - cmin;
+    float scale = ext > 0.0f ? 2097152.0f / ext : 0.0f;
+    float q = (c - cmin) * scale;
+    q = fminf(fmaxf(q, 0.0f), 2097151.0f);
+    return (uint32_t)q;
+}
+
+__global__ void k_morton(const float* __restrict__ boxes, uint32_t n, const uint32_t* __restrict__ cb_ord,
+                         uint64_t* __restrict__ keys, uint32_t* __restrict__ vals)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t q[3];
+    for (int k = 0; k < 3; ++k) {
+        float c = (boxes[6 * (size_t)i + k] + boxes[6 * (size_t)i + 3 + k]) * 0.5f;
+        q[k] = quantize21(c, ord2f(cb_ord[k]), ord2f(cb_ord[3 + k]));
+    }
+    keys[i] = (expand21(q[0]) << 2) | (expand21(q[1]) << 1) | expand21(q[2]);
+    vals[i] = i;
+}
+
+// ---------------------------------------------------------------- stable LSD radix sort, 8-bit digits
+constexpr int kSortItems = 16;                       // sub-tiles of 256 keys per block
+constexpr int kSortTile = kBlock * kSortItems;
+
+__global__ void k_sort_hist(const uint64_t* __restrict__ keys, uint32_t n, int shift, uint32_t n_blocks, uint32_t* __restrict__ hist)
+{
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    size_t base = (size_t)blockIdx.x * kSortTile;
+    for (int s = 0; s < kSortItems; ++s) {
+        size_t idx = base + (size_t)s * kBlock + threadIdx.x;
+        if (idx < n) atomicAdd(&h[(uint32_t)(keys[idx] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    hist[(size_t)threadIdx.x * n_blocks + blockIdx.x] = h[threadIdx.x];
+}
+
+__global__ void k_sort_scatter(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t n, int shift,
+                               uint32_t n_blocks, const uint32_t* __restrict__ hist_scanned,
+                               uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out)
+{
+    __shared__ uint32_t base[256];
+    __shared__ uint32_t wcount[4][256];
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    base[tid] = hist_scanned[(size_t)tid * n_blocks + blockIdx.x];
+    size_t tile = (size_t)blockIdx.x * kSortTile;
+    for (int s = 0; s < kSortItems; ++s) {
+        size_t idx = tile + (size_t)s * kBlock + tid;
+        bool valid = idx < n;
+        uint64_t key = valid ? keys_in[idx] : 0;
+        uint32_t val = valid ? vals_in[idx] : 0;
+        uint32_t digit = (uint32_t)(key >> shift) & 255u;
+        for (int w = 0; w < 4; ++w) wcount[w][tid] = 0;
+        __syncthreads();
+        // lanes of this wave holding the same digit
+        unsigned long long mask = __ballot(valid);
+        for (int b = 0; b < 8; ++b) {
+            unsigned long long bal = __ballot((digit >> b) & 1u);
+            mask &= ((digit >> b) & 1u) ? bal : ~bal;
+        }
+        uint32_t rank = __popcll(mask & ((1ull << lane) - 1ull));
+        if (valid && rank == 0) wcount[wave][digit] = __popcll(mask);
+        __syncthreads();
+        if (valid) {
+            uint32_t off = base[digit] + rank;
+            for (uint32_t w = 0; w < wave; ++w) off += wcount[w][digit];
+            keys_out[off] = key;
+            vals_out[off] = val;
+        }
+        __syncthreads();
+        base[tid] += wcount[0][tid] + wcount[1][tid] + wcount[2][tid] + wcount[3][tid];
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------- exclusive scan (u32)
+__global__ void k_scan_block(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t n, uint32_t* __restrict__ block_sums)
+{
+    __shared__ uint32_t wsum[4];
+    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    uint32_t v = i < n ? in[i] : 0;
+    uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t x = v;
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t y = __shfl_up(x, off);
+        if (lane >= (uint32_t)off) x += y;
+    }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    uint32_t add = 0;
+    for (uint32_t w = 0; w < wave; ++w) add += wsum[w];
+    if (i < n) out[i] = x - v + add;
+    if (threadIdx.x == kBlock - 1) block_sums[blockIdx.x] = x + add;
+}
+// one block walks the block sums in order (n_blocks is small: n / 256)
+__global__ void k_scan_sums(uint32_t* __restrict__ sums, uint32_t n_blocks, uint32_t* __restrict__ total)
+{
+    __shared__ uint32_t wsum[4];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t start = 0; start < n_blocks; start += kBlock) {
+        uint32_t i = start + threadIdx.x;
+        uint32_t v = i < n_blocks ? sums[i] : 0;
+        uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        uint32_t x = v;
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t y = __shfl_up(x, off);
+            if (lane >= (uint32_t)off) x += y;
+        }
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        uint32_t add = carry;
+        for (uint32_t w = 0; w < wave; ++w) add += wsum[w];
+        if (i < n_blocks) sums[i] = x - v + add;
+        __syncthreads();
+        if (threadIdx.x == kBlock - 1) carry = x + add;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && total) *total = carry;
+}
+__global__ void k_scan_add(uint32_t* __restrict__ out, uint32_t n, const uint32_t* __restrict__ block_sums)
+{
+    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) out[i] += block_sums[blockIdx.x];
+}
+
+// ---------------------------------------------------------------- Karras 2012 radix tree
+__device__ __forceinline__ int lcp(const uint64_t* __restrict__ keys, int n, int i, int j)
+{
+    if (j < 0 || j >= n) return -1;
+    uint64_t a = keys[i], b = keys[j];
+    if (a == b) return 64 + __clz((uint32_t)i ^ (uint32_t)j);
+    return __clzll((long long)(a ^ b));
+}
+
+// inner node i in [0, n-2]; child encoding: >= 0 inner index, < 0 : ~leaf position
+__global__ void k_karras(const uint64_t* __restrict__ keys, int n, int* __restrict__ left, int* __restrict__ right,
+                         uint32_t* __restrict__ rng_lo, int* __restrict__ parent)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    int d = (lcp(keys, n, i, i + 1) - lcp(keys, n, i, i - 1)) >= 0 ? 1 : -1;
+    int dmin = lcp(keys, n, i, i - d);
+    int lmax = 2;
+    while (lcp(keys, n, i, i + lmax * d) > dmin) lmax *= 2;
+    int l = 0;
+    for (int t = lmax / 2; t >= 1; t /= 2)
+        if (lcp(keys, n, i, i + (l + t) * d) > dmin) l += t;
+    int j = i + l * d;
+    int dnode = lcp(keys, n, i, j);
+    int s = 0;
+    for (int t = (l + 1) / 2;; t = (t + 1) / 2) {
+        if (lcp(keys, n, i, i + (s + t) * d) > dnode) s += t;
+        if (t == 1) break;
+    }
+    int gamma = i + s * d + min(d, 0);
+    int lo = min(i, j), hi = max(i, j);
+    rng_lo[i] = (uint32_t)lo;
+    if (lo == gamma) left[i] = ~gamma; else { left[i] = gamma; parent[gamma] = i; }
+    if (hi == gamma + 1) right[i] = ~(gamma + 1); else { right[i] = gamma + 1; parent[gamma + 1] = i; }
+    if (i == 0) parent[0] = -1;
+}
+
+// ---------------------------------------------------------------- bottom-up passes
+struct InnerData {       // per inner node
+    float lo[3], hi[3];
+    uint32_t count;
+    float cost;
+};
+
+__device__ __forceinline__ float half_area(const float lo[3], const float hi[3])
+{
+    float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+    return __builtin_fmaf(dz, dx, __builtin_fmaf(dy, dz, dx * dy));
+}
+
+// One pass: every inner node whose children were finished in an earlier pass finishes now.
+// done[i] = pass number (>0) in which node i was finished.  A child finished in THIS pass reads
+// as unfinished whichever value the racing load returns, so the outcome is schedule independent.
+__global__ void k_refit_pass(int n_inner, uint32_t pass, const int* __restrict__ left, const int* __restrict__ right,
+                             const float* __restrict__ boxes, const uint32_t* __restrict__ order,
+                             InnerData* __restrict__ data, uint8_t* __restrict__ collapsed, uint32_t* __restrict__ done,
+                             uint32_t max_leaf, uint32_t* __restrict__ n_done)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_inner) return;
+    if (done[i]) return;
+    int l = left[i], r = right[i];
+    if (l >= 0) { uint32_t dl = done[l]; if (dl == 0 || dl >= pass) return; }
+    if (r >= 0) { uint32_t dr = done[r]; if (dr == 0 || dr >= pass) return; }
+    float llo[3], lhi[3], rlo[3], rhi[3], lcost, rcost; uint32_t lc, rc;
+    if (l >= 0) { for (int k = 0; k < 3; ++k) { llo[k] = data[l].lo[k]; lhi[k] = data[l].hi[k]; } lc = data[l].count; lcost = data[l].cost; }
+    else { const float* b = boxes + 6 * (size_t)order[~l]; for (int k = 0; k < 3; ++k) { llo[k] = b[k]; lhi[k] = b[3 + k]; } lc = 1; lcost = half_area(llo, lhi); }
+    if (r >= 0) { for (int k = 0; k < 3; ++k) { rlo[k] = data[r].lo[k]; rhi[k] = data[r].hi[k]; } rc = data[r].count; rcost = data[r].cost; }
+    else { const float* b = boxes + 6 * (size_t)order[~r]; for (int k = 0; k < 3; ++k) { rlo[k] = b[k]; rhi[k] = b[3 + k]; } rc = 1; rcost = half_area(rlo, rhi); }
+    InnerData d;
+    for (int k = 0; k < 3; ++k) { d.lo[k] = fminf(llo[k], rlo[k]); d.hi[k] = fmaxf(lhi[k], rhi[k]); }
+    d.count = lc + rc;
+    float A = half_area(d.lo, d.hi);
+    float cint = A + (lcost + rcost);
+    float cleaf = (float)d.count * A;
+    bool col = (i != 0) && d.count <= max_leaf && cleaf <= cint;
+    d.cost = col ? cleaf : cint;
+    data[i] = d;
+    collapsed[i] = col ? 1 : 0;
+    done[i] = pass;
+    atomicAdd(n_done, 1u);
+}
+
+__global__ void k_alive(int n_inner, const int* __restrict__ parent, const InnerData* __restrict__ data,
+                        const uint8_t* __restrict__ collapsed, uint32_t max_leaf, uint32_t* __restrict__ alive)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_inner) return;
+    bool dead = collapsed[i] != 0;
+    for (int p = parent[i]; !dead && p >= 0 && data[p].count <= max_leaf; p = parent[p])
+        if (collapsed[p]) dead = true;
+    alive[i] = dead ? 0u : 1u;
+}
+
+__global__ void k_emit(int n_inner, const int* __restrict__ left, const int* __restrict__ right, const uint32_t* __restrict__ rng_lo,
+                       const float* __restrict__ boxes, const uint32_t* __restrict__ order, const InnerData* __restrict__ data,
+                       const uint8_t* __restrict__ collapsed, const uint32_t* __restrict__ alive, const uint32_t* __restrict__ new_index,
+                       PtBvhNode* __restrict__ nodes)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_inner || !alive[i]) return;
+    PtBvhNode nd;
+    nd.aux0 = nd.aux1 = 0;
+    int ch[2] = { left[i], right[i] };
+    for (int s = 0; s < 2; ++s) {
+        int c = ch[s];
+        float* lo = s == 0 ? nd.lo0 : nd.lo1;
+        float* hi = s == 0 ? nd.hi0 : nd.hi1;
+        int ref;
+        if (c < 0) {
+            const float* b = boxes + 6 * (size_t)order[~c];
+            for (int k = 0; k < 3; ++k) { lo[k] = b[k]; hi[k] = b[3 + k]; }
+            ref = ~(int)(((uint32_t)(~c) << 3) | 0u);
+        } else {
+            for (int k = 0; k < 3; ++k) { lo[k] = data[c].lo[k]; hi[k] = data[c].hi[k]; }
+            ref = collapsed[c] ? ~(int)((rng_lo[c] << 3) | (data[c].count - 1u)) : (int)new_index[c];
+        }
+        if (s == 0) nd.c0 = ref; else nd.c1 = ref;
+    }
+    nodes[new_index[i]] = nd;
+}
+
+// 48-byte triangle record per sorted slot: (v0.xyz, v1.x) (v1.yz, v2.xy) (v2.z, bits(prim), 0, 0)
+__global__ void k_pack_tris(const uint8_t* __restrict__ vertices, uint32_t stride, const uint32_t* __restrict__ indices,
+                            const uint32_t* __restrict__ order, uint32_t n, float4* __restrict__ tris)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t p = order[i];
+    const float* a = (const float*)(vertices + (size_t)indices[3 * p + 0] * stride);
+    const float* b = (const float*)(vertices + (size_t)indices[3 * p + 1] * stride);
+    const float* c = (const float*)(vertices + (size_t)indices[3 * p + 2] * stride);
+    tris[3 * (size_t)i + 0] = make_float4(a[0], a[1], a[2], b[0]);
+    tris[3 * (size_t)i + 1] = make_float4(b[1], b[2], c[0], c[1]);
+    tris[3 * (size_t)i + 2] = make_float4(c[2], __uint_as_float(p), 0.0f, 0.0f);
+}
+
+inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+
+struct DevMem {   // frees everything it allocated when it goes out of scope
+    std::vector<void*> ptrs;
+    template <typename T> hipError_t alloc(T** p, size_t count)
+    {
+        void* q = nullptr;
+        hipError_t e = hipMalloc(&q, count * sizeof(T) > 0 ? count * sizeof(T) : 16);
+        if (e == hipSuccess) { ptrs.push_back(q); *p = (T*)q; }
+        return e;
+    }
+    void release(void* p) { for (auto& q : ptrs) if (q == p) q = nullptr; }
+    ~DevMem() { for (void* q : ptrs) if (q) (void)hipFree(q); }
+};
+
+int scan_exclusive(hipStream_t st, DevMem& mem, const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* total_dev)
+{
+    uint32_t nb = div_up(n, kBlock);
+    uint32_t* sums = nullptr;
+    PT_HIP_CHECK(mem.alloc(&sums, nb));
+    k_scan_block<<<nb, kBlock, 0, st>>>(in, out, n, sums);
+    k_scan_sums<<<1, kBlock, 0, st>>>(sums, nb, total_dev);
+    k_scan_add<<<nb, kBlock, 0, st>>>(out, n, sums);
+    PT_HIP_CHECK(hipGetLastError());
+    return PT_OK;
+}
+
+int radix_sort_pairs(hipStream_t st, DevMem& mem, uint64_t** keys, uint32_t** vals, uint32_t n, int key_bits)
+{
+    uint64_t* keys_alt = nullptr; uint32_t* vals_alt = nullptr; uint32_t* hist = nullptr; uint32_t* hist_scanned = nullptr;
+    uint32_t nb = div_up(n, kSortTile);
+    PT_HIP_CHECK(mem.alloc(&keys_alt, n));
+    PT_HIP_CHECK(mem.alloc(&vals_alt, n));
+    PT_HIP_CHECK(mem.alloc(&hist, (size_t)256 * nb));
+    PT_HIP_CHECK(mem.alloc(&hist_scanned, (size_t)256 * nb));
+    uint64_t* kin = *keys; uint32_t* vin = *vals; uint64_t* kout = keys_alt; uint32_t* vout = vals_alt;
+    for (int shift = 0; shift < key_bits; shift += 8) {
+        k_sort_hist<<<nb, kBlock, 0, st>>>(kin, n, shift, nb, hist);
+        int rc = scan_exclusive(st, mem, hist, hist_scanned, 256 * nb, nullptr);
+        if (rc) return rc;
+        k_sort_scatter<<<nb, kBlock, 0, st>>>(kin, vin, n, shift, nb, hist_scanned, kout, vout);
+        std::swap(kin, kout); std::swap(vin, vout);
+    }
+    PT_HIP_CHECK(hipGetLastError());
+    *keys = kin; *vals = vin;
+    return PT_OK;
+}
+
+} // namespace
+
+int pt_build_lbvh(PtContext* ctx, const float* boxes, uint32_t n, uint32_t max_leaf,
+                  PtBvhNode** nodes_out, uint32_t* node_count_out, uint32_t** leaf_prims_out, uint64_t** sorted_keys_out)
+{
+    hipStream_t st = ctx->stream;
+    DevMem mem;
+    uint32_t* cb = nullptr; uint64_t* keys = nullptr; uint32_t* vals = nullptr;
+    PT_HIP_CHECK(mem.alloc(&cb, 8));
+    PT_HIP_CHECK(mem.alloc(&keys, n));
+    PT_HIP_CHECK(mem.alloc(&vals, n));
+    PT_HIP_CHECK(hipMemsetAsync(cb, 0xFF, 12, st));
+    PT_HIP_CHECK(hipMemsetAsync(cb + 3, 0x00, 12, st));
+    uint32_t nb = div_up(n, kBlock);
+    k_centroid_bounds<<<nb, kBlock, 0, st>>>(boxes, n, cb);
+    k_morton<<<nb, kBlock, 0, st>>>(boxes, n, cb, keys, vals);
+    PT_HIP_CHECK(hipGetLastError());
+    int rc = radix_sort_pairs(st, mem, &keys, &vals, n, 64);
+    if (rc) return rc;
+
+    // results that outlive this call
+    uint32_t* leaf_prims = nullptr; uint64_t* sorted_keys = nullptr; PtBvhNode* nodes = nullptr;
+    PT_HIP_CHECK(hipMalloc((void**)&leaf_prims, sizeof(uint32_t) * n));
+    PT_HIP_CHECK(hipMalloc((void**)&sorted_keys, sizeof(uint64_t) * n));
+    PT_HIP_CHECK(hipMemcpyAsync(leaf_prims, vals, sizeof(uint32_t) * n, hipMemcpyDeviceToDevice, st));
+    PT_HIP_CHECK(hipMemcpyAsync(sorted_keys, keys, sizeof(uint64_t) * n, hipMemcpyDeviceToDevice, st));
+    auto fail = [&](int code) { (void)hipFree(leaf_prims); (void)hipFree(sorted_keys); if (nodes) (void)hipFree(nodes); return code; };
+
+    if (n == 1) {
+        float b[6];
+        if (hipMemcpyAsync(b, boxes, 24, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+            pt_set_error("pt_build_lbvh: copy of the single box failed"); return fail(PT_ERROR_HIP);
+        }
+        PtBvhNode nd; memset(&nd, 0, sizeof nd);
+        const float inf = std::numeric_limits<float>::infinity();
+        for (int k = 0; k < 3; ++k) { nd.lo0[k] = b[k]; nd.hi0[k] = b[3 + k]; nd.lo1[k] = inf; nd.hi1[k] = -inf; }
+        nd.c0 = ~0; nd.c1 = std::numeric_limits<int32_t>::min();
+        if (hipMalloc((void**)&nodes, sizeof nd) != hipSuccess || hipMemcpy(nodes, &nd, sizeof nd, hipMemcpyHostToDevice) != hipSuccess) {
+            pt_set_error("pt_build_lbvh: node upload failed"); return fail(PT_ERROR_HIP);
+        }
+        *nodes_out = nodes; *node_count_out = 1; *leaf_prims_out = leaf_prims; *sorted_keys_out = sorted_keys;
+        return PT_OK;
+    }
+
+    const int ni = (int)n - 1;
+    int *left = nullptr, *right = nullptr, *parent = nullptr; uint32_t* rng_lo = nullptr;
+    InnerData* data = nullptr; uint8_t* collapsed = nullptr; uint32_t* done = nullptr; uint32_t* n_done = nullptr;
+    uint32_t* alive = nullptr; uint32_t* new_index = nullptr; uint32_t* total = nullptr;
+    hipError_t e = hipSuccess;
+    if ((e = mem.alloc(&left, ni)) || (e = mem.alloc(&right, ni)) || (e = mem.alloc(&parent, ni)) || (e = mem.alloc(&rng_lo, ni)) ||
+        (e = mem.alloc(&data, ni)) || (e = mem.alloc(&collapsed, ni)) || (e = mem.alloc(&done, ni)) || (e = mem.alloc(&n_done, 4)) ||
+        (e = mem.alloc(&alive, ni)) || (e = mem.alloc(&new_index, ni)) || (e = mem.alloc(&total, 4))) {
+        pt_set_error("pt_build_lbvh: hipMalloc failed: %s", hipGetErrorString(e)); return fail(PT_ERROR_OUT_OF_MEMORY);
+    }
+    uint32_t nbi = div_up((uint32_t)ni, kBlock);
+    (void)hipMemsetAsync(done, 0, sizeof(uint32_t) * ni, st);
+    (void)hipMemsetAsync(n_done, 0, 16, st);
+    k_karras<<<nbi, kBlock, 0, st>>>(keys, (int)n, left, right, rng_lo, parent);
+    // bottom-up: one launch per tree level; a kernel boundary is the only hand-off between levels
+    uint32_t pass = 1, finished = 0;
+    while (finished < (uint32_t)ni) {
+        for (int k = 0; k < 8; ++k, ++pass)
+            k_refit_pass<<<nbi, kBlock, 0, st>>>(ni, pass, left, right, boxes, vals, data, collapsed, done, max_leaf, n_done);
+        if (hipMemcpyAsync(&finished, n_done, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+            pt_set_error("pt_build_lbvh: refit failed: %s", hipGetErrorString(hipGetLastError())); return fail(PT_ERROR_HIP);
+        }
+        if (pass > 4096) { pt_set_error("pt_build_lbvh: refit did not converge"); return fail(PT_ERROR_HIP); }
+    }
+    k_alive<<<nbi, kBlock, 0, st>>>(ni, parent, data, collapsed, max_leaf, alive);
+    rc = scan_exclusive(st, mem, alive, new_index, (uint32_t)ni, total);
+    if (rc) return fail(rc);
+    uint32_t n_alive = 0;
+    if (hipMemcpyAsync(&n_alive, total, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+        pt_set_error("pt_build_lbvh: scan failed: %s", hipGetErrorString(hipGetLastError())); return fail(PT_ERROR_HIP);
+    }
+    if (hipMalloc((void**)&nodes, sizeof(PtBvhNode) * (size_t)n_alive) != hipSuccess) { pt_set_error("pt_build_lbvh: out of memory"); return fail(PT_ERROR_OUT_OF_MEMORY); }
+    k_emit<<<nbi, kBlock, 0, st>>>(ni, left, right, rng_lo, boxes, vals, data, collapsed, alive, new_index, nodes);
+    if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) {
+        pt_set_error("pt_build_lbvh: emit failed"); return fail(PT_ERROR_HIP);
+    }
+    *nodes_out = nodes; *node_count_out = n_alive; *leaf_prims_out = leaf_prims; *sorted_keys_out = sorted_keys;
+    return PT_OK;
+}
+
+// =============================================================================================
+extern "C" {
+
+int pt_blas_build(PtContext* ctx, const void* vertices_dev, uint32_t vertex_stride, uint32_t max_vertex,
+                  const uint32_t* indices_dev, uint32_t prim_count, uint32_t max_leaf, PtBlas** out)
+{
+    PT_REQUIRE(ctx && vertices_dev && indices_dev && out, "null argument");
+    PT_REQUIRE(prim_count > 0, "prim_count must be positive");
+    PT_REQUIRE(prim_count < (1u << 28), "prim_count must be below 2^28");
+    PT_REQUIRE(vertex_stride >= 12 && vertex_stride % 4 == 0, "vertex_stride must be a multiple of 4 and at least 12");
+    if (max_leaf == 0) max_leaf = 4;
+    PT_REQUIRE(max_leaf <= 8, "max_leaf must be at most 8");
+    PT_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    hipEvent_t ev0, ev1;
+    PT_HIP_CHECK(hipEventCreate(&ev0)); PT_HIP_CHECK(hipEventCreate(&ev1));
+    PT_HIP_CHECK(hipEventRecord(ev0, st));
+    DevMem mem;
+    uint32_t* scal = nullptr; float* boxes = nullptr;
+    PT_HIP_CHECK(mem.alloc(&scal, 8));          // [0] maxabs bits, [1..6] root box (ordered)
+    PT_HIP_CHECK(mem.alloc(&boxes, (size_t)prim_count * 6));
+    PT_HIP_CHECK(hipMemsetAsync(scal, 0, 4, st));
+    PT_HIP_CHECK(hipMemsetAsync(scal + 1, 0xFF, 12, st));
+    PT_HIP_CHECK(hipMemsetAsync(scal + 4, 0x00, 12, st));
+    uint32_t nb = div_up(prim_count, kBlock);
+    const uint8_t* v = (const uint8_t*)vertices_dev;
+    k_blas_maxabs<<<nb, kBlock, 0, st>>>(v, vertex_stride, indices_dev, prim_count, scal);
+    k_tri_boxes<<<nb, kBlock, 0, st>>>(v, vertex_stride, indices_dev, prim_count, scal, boxes, scal + 1);
+    PT_HIP_CHECK(hipGetLastError());
+    PtBlas* b = new PtBlas();
+    memset(b, 0, sizeof *b);
+    b->ctx = ctx; b->vertices = v; b->stride = vertex_stride; b->max_vertex = max_vertex;
+    b->indices = indices_dev; b->prim_count = prim_count; b->max_leaf = max_leaf;
+    int rc = pt_build_lbvh(ctx, boxes, prim_count, max_leaf, &b->nodes, &b->node_count, &b->leaf_prims, &b->sorted_keys);
+    if (rc) { delete b; return rc; }
+    uint32_t host_scal[7];
+    hipError_t e = hipMalloc((void**)&b->tris, sizeof(float4) * 3 * (size_t)prim_count);
+    if (e == hipSuccess) {
+        k_pack_tris<<<nb, kBlock, 0, st>>>(v, vertex_stride, indices_dev, b->leaf_prims, prim_count, b->tris);
+        e = hipMemcpyAsync(host_scal, scal, sizeof host_scal, hipMemcpyDeviceToHost, st);
+    }
+    if (e == hipSuccess) e = hipEventRecord(ev1, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { pt_set_error("pt_blas_build: %s", hipGetErrorString(e)); pt_blas_destroy(b); return PT_ERROR_HIP; }
+    float maxabs; memcpy(&maxabs, &host_scal[0], 4);
+    b->delta = maxabs * 3.0517578125e-05f;
+    for (int k = 0; k < 3; ++k) { b->root_lo[k] = ord2f(host_scal[1 + k]); b->root_hi[k] = ord2f(host_scal[4 + k]); }
+    (void)hipEventElapsedTime(&b->build_ms, ev0, ev1);
+    (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
+    *out = b;
+    return PT_OK;
+}
+
+int pt_blas_destroy(PtBlas* b)
+{
+    if (!b) return PT_OK;
+    (void)hipFree(b->nodes); (void)hipFree(b->tris); (void)hipFree(b->leaf_prims); (void)hipFree(b->sorted_keys);
+    delete b;
+    return PT_OK;
+}
+
+int pt_blas_info(const PtBlas* b, PtAsInfo* out)
+{
+    PT_REQUIRE(b && out, "null argument");
+    out->node_count = b->node_count; out->prim_count = b->prim_count;
+    for (int k = 0; k < 3; ++k) { out->root_lo[k] = b->root_lo[k]; out->root_hi[k] = b->root_hi[k]; }
+    out->delta = b->delta; out->build_ms = b->build_ms;
+    return PT_OK;
+}
+
+int pt_blas_download(const PtBlas* b, PtBvhNode* nodes, uint32_t* leaf_prims, uint64_t* sorted_keys)
+{
+    PT_REQUIRE(b, "null argument");
+    PT_HIP_CHECK(hipSetDevice(b->ctx->device));
+    if (nodes) PT_HIP_CHECK(hipMemcpy(nodes, b->nodes, sizeof(PtBvhNode) * b->node_count, hipMemcpyDeviceToHost));
+    if (leaf_prims) PT_HIP_CHECK(hipMemcpy(leaf_prims, b->leaf_prims, sizeof(uint32_t) * b->prim_count, hipMemcpyDeviceToHost));
+    if (sorted_keys) PT_HIP_CHECK(hipMemcpy(sorted_keys, b->sorted_keys, sizeof(uint64_t) * b->prim_count, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+// Inverse of a row-major 3x4 affine transform in binary64 by cofactors, rounded once to binary32:
+// the world->object matrix the driver would expose as gl_WorldToObjectEXT.
+static void invert_transform(const float m[12], float w[12])
+{
+    double a00 = m[0], a01 = m[1], a02 = m[2], t0 = m[3];
+    double a10 = m[4], a11 = m[5], a12 = m[6], t1 = m[7];
+    double a20 = m[8], a21 = m[9], a22 = m[10], t2 = m[11];
+    double c00 = a11 * a22 - a12 * a21;
+    double c01 = a12 * a20 - a10 * a22;
+    double c02 = a10 * a21 - a11 * a20;
+    double det = (a00 * c00 + a01 * c01) + a02 * c02;
+    double i00 = c00 / det, i01 = (a02 * a21 - a01 * a22) / det, i02 = (a01 * a12 - a02 * a11) / det;
+    double i10 = c01 / det, i11 = (a00 * a22 - a02 * a20) / det, i12 = (a02 * a10 - a00 * a12) / det;
+    double i20 = c02 / det, i21 = (a01 * a20 - a00 * a21) / det, i22 = (a00 * a11 - a01 * a10) / det;
+    w[0] = (float)i00; w[1] = (float)i01; w[2] = (float)i02;  w[3] = (float)(-((i00 * t0 + i01 * t1) + i02 * t2));
+    w[4] = (float)i10; w[5] = (float)i11; w[6] = (float)i12;  w[7] = (float)(-((i10 * t0 + i11 * t1) + i12 * t2));
+    w[8] = (float)i20; w[9] = (float)i21; w[10] = (float)i22; w[11] = (float)(-((i20 * t0 + i21 * t1) + i22 * t2));
+}
+
+int pt_tlas_build(PtContext* ctx, const PtInstance* instances, uint32_t n, PtTlas** out)
+{
+    PT_REQUIRE(ctx && instances && out, "null argument");
+    PT_REQUIRE(n > 0, "at least one instance is required");
+    PT_REQUIRE(n <= (1u << 24), "instance count exceeds the 24-bit custom index");
+    PT_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    hipEvent_t ev0, ev1;
+    PT_HIP_CHECK(hipEventCreate(&ev0)); PT_HIP_CHECK(hipEventCreate(&ev1));
+    PT_HIP_CHECK(hipEventRecord(ev0, st));
+    PtTlas* t = new PtTlas();
+    t->ctx = ctx; t->n = n; t->nodes = nullptr; t->leaf_inst = nullptr; t->inst = nullptr; t->shade_inst = nullptr;
+    t->host_boxes.resize((size_t)n * 6); t->host_w2o.resize((size_t)n * 12);
+    std::vector<PtDevInstance> di(n);
+    std::vector<PtDevShadeInstance> ds(n);
+    const float inf = std::numeric_limits<float>::infinity();
+    for (int k = 0; k < 3; ++k) { t->root_lo[k] = inf; t->root_hi[k] = -inf; }
+    for (uint32_t i = 0; i < n; ++i) {
+        const PtInstance& I = instances[i];
+        const PtBlas* b = (const PtBlas*)(uintptr_t)I.accelerationStructureReference;
+        if (!b) { delete t; pt_set_error("pt_tlas_build: instance %u has a null BLAS reference", i); return PT_ERROR_INVALID_ARGUMENT; }
+        const float* m = I.transform;
+        float w2o[12];
+        invert_transform(m, w2o);
+        // world box: the eight corners of the BLAS root box through object->world, then padded
+        float lo[3] = { inf, inf, inf }, hi[3] = { -inf, -inf, -inf };
+        for (int c = 0; c < 8; ++c) {
+            float px = (c & 1) ? b->root_hi[0] : b->root_lo[0];
+            float py = (c & 2) ? b->root_hi[1] : b->root_lo[1];
+            float pz = (c & 4) ? b->root_hi[2] : b->root_lo[2];
+            for (int r = 0; r < 3; ++r) {
+                float q = __builtin_fmaf(m[4 * r], px, __builtin_fmaf(m[4 * r + 1], py, __builtin_fmaf(m[4 * r + 2], pz, m[4 * r + 3])));
+                lo[r] = q < lo[r] ? q : lo[r];
+                hi[r] = q > hi[r] ? q : hi[r];
+            }
+        }
+        float maxabs = 0.0f;
+        for (int r = 0; r < 3; ++r) { maxabs = fmaxf(maxabs, fabsf(lo[r])); maxabs = fmaxf(maxabs, fabsf(hi[r])); }
+        float dw = maxabs * 3.0517578125e-05f;
+        for (int r = 0; r < 3; ++r) {
+            lo[r] -= dw; hi[r] += dw;
+            t->host_boxes[6 * (size_t)i + r] = lo[r]; t->host_boxes[6 * (size_t)i + 3 + r] = hi[r];
+            t->root_lo[r] = fminf(t->root_lo[r], lo[r]); t->root_hi[r] = fmaxf(t->root_hi[r], hi[r]);
+        }
+        memcpy(&t->host_w2o[12 * (size_t)i], w2o, 48);
+        uint32_t custom = I.instanceCustomIndexAndMask & 0xFFFFFFu;
+        float customf; memcpy(&customf, &custom, 4);
+        for (int r = 0; r < 3; ++r) {
+            di[i].q[r] = make_float4(w2o[4 * r], w2o[4 * r + 1], w2o[4 * r + 2], w2o[4 * r + 3]);
+            ds[i].o2w[r] = make_float4(m[4 * r], m[4 * r + 1], m[4 * r + 2], m[4 * r + 3]);
+            ds[i].w2o[r] = di[i].q[r];
+        }
+        ds[i].meta = make_float4(customf, 0.0f, 0.0f, 0.0f);
+        di[i].q[3] = make_float4(lo[0], lo[1], lo[2], b->delta);
+        di[i].q[4] = make_float4(hi[0], hi[1], hi[2], customf);
+        uint64_t pn = (uint64_t)(uintptr_t)b->nodes, pt = (uint64_t)(uintptr_t)b->tris;
+        uint32_t w[4] = { (uint32_t)pn, (uint32_t)(pn >> 32), (uint32_t)pt, (uint32_t)(pt >> 32) };
+        memcpy(&di[i].q[5], w, 16);
+    }
+    float* boxes_dev = nullptr;
+    hipError_t e = hipMalloc((void**)&boxes_dev, sizeof(float) * 6 * (size_t)n);
+    if (e == hipSuccess) e = hipMemcpyAsync(boxes_dev, t->host_boxes.data(), sizeof(float) * 6 * (size_t)n, hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) { delete t; pt_set_error("pt_tlas_build: %s", hipGetErrorString(e)); return PT_ERROR_HIP; }
+    uint64_t* keys = nullptr;
+    int rc = pt_build_lbvh(ctx, boxes_dev, n, 1, &t->nodes, &t->node_count, &t->leaf_inst, &keys);
+    (void)hipFree(boxes_dev);
+    if (rc) { delete t; return rc; }
+    (void)hipFree(keys);
+    e = hipMalloc((void**)&t->inst, sizeof(PtDevInstance) * n);
+    if (e == hipSuccess) e = hipMalloc((void**)&t->shade_inst, sizeof(PtDevShadeInstance) * n);
+    if (e == hipSuccess) e = hipMemcpyAsync(t->inst, di.data(), sizeof(PtDevInstance) * n, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(t->shade_inst, ds.data(), sizeof(PtDevShadeInstance) * n, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipEventRecord(ev1, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { pt_set_error("pt_tlas_build: %s", hipGetErrorString(e)); pt_tlas_destroy(t); return PT_ERROR_HIP; }
+    (void)hipEventElapsedTime(&t->build_ms, ev0, ev1);
+    (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
+    *out = t;
+    return PT_OK;
+}
+
+int pt_tlas_destroy(PtTlas* t)
+{
+    if (!t) return PT_OK;
+    (void)hipFree(t->nodes); (void)hipFree(t->leaf_inst); (void)hipFree(t->inst); (void)hipFree(t->shade_inst);
+    delete t;
+    return PT_OK;
+}
+
+int pt_tlas_info(const PtTlas* t, PtAsInfo* out)
+{
+    PT_REQUIRE(t && out, "null argument");
+    out->node_count = t->node_count; out->prim_count = t->n;
+    for (int k = 0; k < 3; ++k) { out->root_lo[k] = t->root_lo[k]; out->root_hi[k] = t->root_hi[k]; }
+    out->delta = 0.0f; out->build_ms = t->build_ms;
+    return PT_OK;
+}
+
+int pt_tlas_download(const PtTlas* t, PtBvhNode* nodes, uint32_t* leaf_instances, float* instance_boxes, float* instance_w2o)
+{
+    PT_REQUIRE(t, "null argument");
+    PT_HIP_CHECK(hipSetDevice(t->ctx->device));
+    if (nodes) PT_HIP_CHECK(hipMemcpy(nodes, t->nodes, sizeof(PtBvhNode) * t->node_count, hipMemcpyDeviceToHost));
+    if (leaf_instances) PT_HIP_CHECK(hipMemcpy(leaf_instances, t->leaf_inst, sizeof(uint32_t) * t->n, hipMemcpyDeviceToHost));
+    if (instance_boxes) memcpy(instance_boxes, t->host_boxes.data(), sizeof(float) * 6 * (size_t)t->n);
+    if (instance_w2o) memcpy(instance_w2o, t->host_w2o.data(), sizeof(float) * 12 * (size_t)t->n);
+    return PT_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,148 @@
+// pt_capi.hip -- context, buffers, tables and error reporting of the C ABI (include/pt_hip.h).
+#include "pt_internal.h"
+#include <stdarg.h>
+#include <string.h>
+
+static thread_local char g_error[512] = "";
+
+void pt_set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof g_error, fmt, ap);
+    va_end(ap);
+}
+
+template <typename T>
+static int replace_table(T** dst, uint32_t* n_dst, const T* src, uint32_t n)
+{
+    (void)hipFree(*dst); *dst = nullptr; *n_dst = 0;
+    PT_HIP_CHECK(hipMalloc((void**)dst, sizeof(T) * (n ? n : 1)));
+    if (n) PT_HIP_CHECK(hipMemcpy(*dst, src, sizeof(T) * n, hipMemcpyHostToDevice));
+    *n_dst = n;
+    return PT_OK;
+}
+
+extern "C" {
+
+const char* pt_last_error(void) { return g_error; }
+
+int pt_ctx_create(int device_id, void* hip_stream, PtContext** out)
+{
+    PT_REQUIRE(out, "null argument");
+    int count = 0;
+    PT_HIP_CHECK(hipGetDeviceCount(&count));
+    PT_REQUIRE(device_id >= 0 && device_id < count, "no such device");
+    PT_HIP_CHECK(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    PT_HIP_CHECK(hipGetDeviceProperties(&prop, device_id));
+    PtContext* c = new PtContext();
+    c->device = device_id;
+    c->num_cus = prop.multiProcessorCount;
+    if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
+    else {
+        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete c; pt_set_error("hipStreamCreate failed: %s", hipGetErrorString(e)); return PT_ERROR_HIP; }
+        c->own_stream = true;
+    }
+    *out = c;
+    return PT_OK;
+}
+
+int pt_ctx_destroy(PtContext* c)
+{
+    if (!c) return PT_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    PtWorkspace& w = c->ws;
+    for (int a = 0; a < 2; ++a) for (int k = 0; k < 4; ++k) (void)hipFree(w.q[a][k]);
+    (void)hipFree(w.hits); (void)hipFree(w.path_result); (void)hipFree(w.frame_result);
+    (void)hipFree(w.counters); (void)hipFree(w.stats); (void)hipFree(w.cam); (void)hipFree(w.spill);
+    (void)hipFree(c->materials); (void)hipFree(c->geometry_nodes); (void)hipFree(c->blas_instances); (void)hipFree(c->textures);
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return PT_OK;
+}
+
+int pt_sync(PtContext* c)
+{
+    PT_REQUIRE(c, "null argument");
+    PT_HIP_CHECK(hipSetDevice(c->device));
+    PT_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return PT_OK;
+}
+
+int pt_ctx_set_max_paths(PtContext* c, uint64_t max_paths)
+{
+    PT_REQUIRE(c, "null argument");
+    PT_REQUIRE(max_paths >= 64 && max_paths < (1ull << 32), "max_paths must be in [64, 2^32)");
+    c->max_paths = max_paths;
+    return PT_OK;
+}
+
+int pt_buffer_upload(PtContext* c, const void* host, size_t bytes, void** dev_out)
+{
+    PT_REQUIRE(c && dev_out && (host || bytes == 0), "null argument");
+    PT_HIP_CHECK(hipSetDevice(c->device));
+    void* d = nullptr;
+    PT_HIP_CHECK(hipMalloc(&d, bytes ? bytes : 16));
+    if (bytes) {
+        hipError_t e = hipMemcpy(d, host, bytes, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipFree(d); pt_set_error("hipMemcpy failed: %s", hipGetErrorString(e)); return PT_ERROR_HIP; }
+    }
+    *dev_out = d;
+    return PT_OK;
+}
+
+int pt_buffer_download(PtContext* c, const void* dev, size_t bytes, void* host_out)
+{
+    PT_REQUIRE(c && dev && host_out, "null argument");
+    PT_HIP_CHECK(hipSetDevice(c->device));
+    PT_HIP_CHECK(hipStreamSynchronize(c->stream));
+    PT_HIP_CHECK(hipMemcpy(host_out, dev, bytes, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+int pt_buffer_free(PtContext* c, void* dev)
+{
+    PT_REQUIRE(c, "null argument");
+    PT_HIP_CHECK(hipSetDevice(c->device));
+    PT_HIP_CHECK(hipFree(dev));
+    return PT_OK;
+}
+
+int pt_scene_set_tables(PtContext* c,
+                        const PtMaterial* materials, uint32_t n_materials,
+                        const PtGeometryNode* geometry_nodes, uint32_t n_geometry_nodes,
+                        const PtBLASInstance* blas_instances, uint32_t n_blas_instances,
+                        const PtTextureDesc* textures, uint32_t n_textures)
+{
+    PT_REQUIRE(c, "null argument");
+    PT_REQUIRE((materials || !n_materials) && (geometry_nodes || !n_geometry_nodes) && (blas_instances || !n_blas_instances) && (textures || !n_textures), "null table");
+    // the reference logs and skips the upload above 1024 entries (source/resources/bindless_resources.cpp:85-89)
+    if (n_materials > 1024 || n_geometry_nodes > 1024 || n_blas_instances > 1024 || n_textures > 1024) {
+        pt_set_error("pt_scene_set_tables: a table exceeds 1024 entries");
+        return PT_ERROR_LIMIT;
+    }
+    // every index a shader will follow is checked here once instead of per hit
+    for (uint32_t i = 0; i < n_blas_instances; ++i)
+        PT_REQUIRE(blas_instances[i].firstGeometryIndex < n_geometry_nodes, "BLASInstance.firstGeometryIndex out of range");
+    for (uint32_t i = 0; i < n_geometry_nodes; ++i) {
+        PT_REQUIRE(geometry_nodes[i].materialIndex < n_materials, "GeometryNode.materialIndex out of range");
+        PT_REQUIRE(geometry_nodes[i].vertexBufferDeviceAddress && geometry_nodes[i].indexBufferDeviceAddress, "GeometryNode with a null buffer address");
+    }
+    for (uint32_t i = 0; i < n_materials; ++i)
+        if (materials[i].useAlbedoMap) PT_REQUIRE(materials[i].albedoMapIndex < n_textures, "Material.albedoMapIndex out of range");
+    for (uint32_t i = 0; i < n_textures; ++i)
+        PT_REQUIRE(textures[i].rgba8_dev && textures[i].width && textures[i].height, "empty texture");
+    PT_HIP_CHECK(hipSetDevice(c->device));
+    PT_HIP_CHECK(hipStreamSynchronize(c->stream));
+    int rc;
+    if ((rc = replace_table(&c->materials, &c->n_materials, materials, n_materials))) return rc;
+    if ((rc = replace_table(&c->geometry_nodes, &c->n_geometry_nodes, geometry_nodes, n_geometry_nodes))) return rc;
+    if ((rc = replace_table(&c->blas_instances, &c->n_blas_instances, blas_instances, n_blas_instances))) return rc;
+    if ((rc = replace_table(&c->textures, &c->n_textures, textures, n_textures))) return rc;
+    return PT_OK;
+}
+
+} // extern "C"

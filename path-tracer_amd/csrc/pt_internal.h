@@ -1,0 +1,97 @@
+// pt_internal.h -- structures shared by the translation units of libpt_hip.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+
+#include "../../include/pt_hip.h"
+
+void pt_set_error(const char* fmt, ...);
+
+#define PT_HIP_CHECK(expr)                                                                   \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            pt_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return e_ == hipErrorOutOfMemory ? PT_ERROR_OUT_OF_MEMORY : PT_ERROR_HIP;        \
+        }                                                                                    \
+    } while (0)
+
+#define PT_REQUIRE(cond, msg)                      \
+    do {                                           \
+        if (!(cond)) {                             \
+            pt_set_error("%s: %s", __func__, msg); \
+            return PT_ERROR_INVALID_ARGUMENT;      \
+        }                                          \
+    } while (0)
+
+// ---- device-side records -------------------------------------------------------------------
+// Traversal view of one TLAS instance: six float4.
+//   [0..2] world->object rows; [3] = (box lo.xyz, delta); [4] = (box hi.xyz, bits(custom index));
+//   [5] = (nodes pointer lo/hi, triangles pointer lo/hi)
+struct PtDevInstance { float4 q[6]; };
+// Shading view: object->world rows then world->object rows.
+struct PtDevShadeInstance { float4 o2w[3]; float4 w2o[3]; float4 meta; /* x = bits(custom index) */ };
+
+struct PtBlas {
+    PtContext* ctx;
+    const uint8_t* vertices; uint32_t stride; uint32_t max_vertex;
+    const uint32_t* indices; uint32_t prim_count; uint32_t max_leaf;
+    float delta; float root_lo[3], root_hi[3];
+    uint32_t node_count;
+    PtBvhNode* nodes;        // device, node_count
+    float4* tris;            // device, 3 float4 per sorted slot
+    uint32_t* leaf_prims;    // device, prim ids in sorted order
+    uint64_t* sorted_keys;   // device
+    float build_ms;
+};
+
+struct PtTlas {
+    PtContext* ctx;
+    uint32_t n;
+    uint32_t node_count;
+    PtBvhNode* nodes;               // device
+    uint32_t* leaf_inst;            // device, instance index per sorted slot
+    PtDevInstance* inst;            // device, n
+    PtDevShadeInstance* shade_inst; // device, n
+    std::vector<float> host_boxes;  // n x 6
+    std::vector<float> host_w2o;    // n x 12
+    float root_lo[3], root_hi[3];
+    float build_ms;
+};
+
+struct PtWorkspace {
+    uint64_t paths_cap = 0;
+    float4* q[2][4] = { { nullptr, nullptr, nullptr, nullptr }, { nullptr, nullptr, nullptr, nullptr } };
+    PtHit* hits = nullptr;
+    float4* path_result = nullptr;     // per path: final hitValue (xyz)
+    float* frame_result = nullptr;     // per pixel x 3
+    uint64_t frame_pixels_cap = 0;
+    uint32_t* counters = nullptr;      // queue sizes per depth (+ work counters)
+    uint64_t* stats = nullptr;         // PT_MAX_DEPTH rays-per-depth + paths
+    float* cam = nullptr;              // 32 floats
+    int* spill = nullptr;              // traversal stack overflow, PT_SPILL_STACK ints per persistent thread
+    uint64_t spill_threads = 0;
+};
+
+struct PtContext {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int num_cus = 0;
+    uint64_t max_paths = 1ull << 25;
+    // tables
+    PtMaterial* materials = nullptr; uint32_t n_materials = 0;
+    PtGeometryNode* geometry_nodes = nullptr; uint32_t n_geometry_nodes = 0;
+    PtBLASInstance* blas_instances = nullptr; uint32_t n_blas_instances = 0;
+    PtTextureDesc* textures = nullptr; uint32_t n_textures = 0;
+    PtWorkspace ws;
+    uint32_t last_w = 0, last_h = 0;
+};
+
+// pt_build.hip
+int pt_build_lbvh(PtContext* ctx, const float* prim_boxes_dev /* n x 6: lo, hi */, uint32_t n, uint32_t max_leaf,
+                  PtBvhNode** nodes_out, uint32_t* node_count_out, uint32_t** leaf_prims_out, uint64_t** sorted_keys_out);

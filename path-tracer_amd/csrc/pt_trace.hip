@@ -1,0 +1,486 @@
+// pt_trace.hip -- the wavefront path-tracing pipeline that replaces vkCmdTraceRaysKHR
+// (source/renderer.cpp:122) and the three shaders it runs:
+//   generate   shaders/ray_gen.rgen:21-47   primary ray + per-sample seed + payload reset
+//   intersect  shaders/ray_gen.rgen:54-65   traceRayEXT (software two-level BVH traversal)
+//   shade      shaders/closest_hit.rchit:55-86 and shaders/miss.rmiss:8-21, plus the
+//              bounce bookkeeping of ray_gen.rgen:67-68; survivors are compacted into the next queue
+//   accumulate shaders/ray_gen.rgen:71-87   per-pixel sum over samples, running mean / sum
+//
+// Path state lives in four float4 streams per queue slot (ping-pong between bounces):
+//   q0 = (origin.xyz, bits(seed))   q1 = (direction.xyz, bits(path id))
+//   q2 = (currentWeight.rgb, -)     q3 = (hitValue.rgb, -)
+// so every lane moves 16 bytes per access and a wave moves 1 KiB per instruction.
+// Queue sizes are device-side counters: kernels are launched with a fixed persistent grid and
+// waves pull batches of 64 slots with one atomic each, so a frame needs no host round trip.
+#include "pt_device.h"
+#include <string.h>
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kCounterStride = 64;   // counters: [0,64) queue sizes, [64,128) intersect work, [128,192) shade work
+
+__device__ __forceinline__ uint32_t wave_fetch(uint32_t* counter)
+{
+    uint32_t base = 0;
+    if ((threadIdx.x & 63) == 0) base = atomicAdd(counter, 64u);
+    return __builtin_amdgcn_readfirstlane(base);
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+k_generate(uint32_t n_paths, uint32_t pixel0, uint32_t spp, uint32_t W, uint32_t H, uint32_t frame, uint32_t seed_mode,
+           const float* __restrict__ cam /* 32 floats, device */, float4* __restrict__ q0, float4* __restrict__ q1,
+           float4* __restrict__ q2, float4* __restrict__ q3, uint32_t* __restrict__ counters)
+{
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q == 0) counters[0] = n_paths;
+    if (q >= n_paths) return;
+    const uint32_t pixel = pixel0 + q / spp, s = q % spp;
+    const uint32_t px = pixel % W, py = pixel / W;
+    const float* VI = cam; const float* PI = cam + 16;
+    float uvx = ((float)px + 0.5f) / (float)W;
+    float uvy = ((float)py + 0.5f) / (float)H;
+    float dx = uvx * 2.0f - 1.0f, dy = uvy * 2.0f - 1.0f;
+    float tx = PT_FMA(PI[0], dx, PT_FMA(PI[4], dy, PI[8] + PI[12]));
+    float ty = PT_FMA(PI[1], dx, PT_FMA(PI[5], dy, PI[9] + PI[13]));
+    float tz = PT_FMA(PI[2], dx, PT_FMA(PI[6], dy, PI[10] + PI[14]));
+    pt_normalize(tx, ty, tz);
+    float rx = PT_FMA(VI[0], tx, PT_FMA(VI[4], ty, VI[8] * tz));
+    float ry = PT_FMA(VI[1], tx, PT_FMA(VI[5], ty, VI[9] * tz));
+    float rz = PT_FMA(VI[2], tx, PT_FMA(VI[6], ty, VI[10] * tz));
+    uint32_t v1 = seed_mode == PT_SEED_CLOCK ? (uint32_t)clock64() : frame * spp + s;
+    uint32_t seed = pt_tea(py * W + px, v1);
+    q0[q] = make_float4(VI[12], VI[13], VI[14], __uint_as_float(seed));
+    q1[q] = make_float4(rx, ry, rz, __uint_as_float(q));
+    q2[q] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+    q3[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+k_intersect(PtTlasView tl, const uint32_t* __restrict__ n_rays_ptr, uint32_t* __restrict__ work,
+            const float4* __restrict__ q0, const float4* __restrict__ q1, float tmin, float tmax,
+            PtHit* __restrict__ hits, float* __restrict__ t_out, int* __restrict__ spill)
+{
+    __shared__ int s_stack[PT_LDS_STACK][kBlock];
+    PtStack stk;
+    stk.lds = &s_stack[0][threadIdx.x];
+    stk.lds_stride = kBlock;
+    stk.spill = spill + (size_t)(blockIdx.x * blockDim.x + threadIdx.x) * PT_SPILL_STACK;
+    const uint32_t n = *n_rays_ptr;
+    const uint32_t lane = threadIdx.x & 63;
+    for (;;) {
+        const uint32_t base = wave_fetch(work);
+        if (base >= n) break;
+        const uint32_t i = base + lane;
+        if (i < n) {
+            const float4 o = q0[i], d = q1[i];
+            PtHitRec h;
+            pt_closest_hit(tl, stk, o.x, o.y, o.z, d.x, d.y, d.z, tmin, tmax, h);
+            PtHit out; out.instance = h.inst; out.primitive = h.prim; out.u = h.u; out.v = h.v;
+            hits[i] = out;
+            if (t_out) t_out[i] = h.t;
+        }
+    }
+}
+
+// rays given as packed float3 arrays (pt_intersect entry point): repack into the float4 streams
+__global__ void k_pack_rays(uint32_t n, const float* __restrict__ o, const float* __restrict__ d,
+                            float4* __restrict__ q0, float4* __restrict__ q1, uint32_t* __restrict__ counters)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) counters[0] = n;
+    if (i >= n) return;
+    q0[i] = make_float4(o[3 * (size_t)i], o[3 * (size_t)i + 1], o[3 * (size_t)i + 2], 0.0f);
+    q1[i] = make_float4(d[3 * (size_t)i], d[3 * (size_t)i + 1], d[3 * (size_t)i + 2], 0.0f);
+}
+
+// ------------------------------------------------------------------------------------------------
+struct PtTables {
+    const PtMaterial* materials;
+    const PtGeometryNode* geometry_nodes;
+    const PtBLASInstance* blas_instances;
+    const PtTextureDesc* textures;
+    const PtDevShadeInstance* shade_inst;
+};
+
+struct __attribute__((aligned(4))) PtVertex { float px, py, pz, nx, ny, nz, tu, tv; };
+
+// texture(textures[i], uv): LINEAR min/mag, REPEAT, single level, R8G8B8A8_UNORM
+// (include/resources/gpu_resources.hpp:44-63, source/model_loader.cpp:18).
+__device__ __forceinline__ void pt_texture_rgb(const PtTextureDesc& tex, float u, float v, float& r, float& g, float& b)
+{
+    const int W = (int)tex.width, H = (int)tex.height;
+    const uint32_t* texels = (const uint32_t*)(uintptr_t)tex.rgba8_dev;
+    float U = PT_FMA(u, (float)W, -0.5f), V = PT_FMA(v, (float)H, -0.5f);
+    float fu = floorf(U), fv = floorf(V);
+    float a = U - fu, bb = V - fv;
+    long long i0 = (long long)fu, j0 = (long long)fv;
+    int x0 = (int)(i0 % W); if (x0 < 0) x0 += W;
+    int x1 = (int)((i0 + 1) % W); if (x1 < 0) x1 += W;
+    int y0 = (int)(j0 % H); if (y0 < 0) y0 += H;
+    int y1 = (int)((j0 + 1) % H); if (y1 < 0) y1 += H;
+    uint32_t t00 = texels[(size_t)y0 * W + x0], t10 = texels[(size_t)y0 * W + x1];
+    uint32_t t01 = texels[(size_t)y1 * W + x0], t11 = texels[(size_t)y1 * W + x1];
+    float out[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        float c00 = (float)((t00 >> (8 * ch)) & 255u) / 255.0f, c10 = (float)((t10 >> (8 * ch)) & 255u) / 255.0f;
+        float c01 = (float)((t01 >> (8 * ch)) & 255u) / 255.0f, c11 = (float)((t11 >> (8 * ch)) & 255u) / 255.0f;
+        float r0 = PT_FMA(a, c10 - c00, c00);
+        float r1 = PT_FMA(a, c11 - c01, c01);
+        out[ch] = PT_FMA(bb, r1 - r0, r0);
+    }
+    r = out[0]; g = out[1]; b = out[2];
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_shade(PtTables tb, uint32_t depth, uint32_t max_depth, const uint32_t* __restrict__ n_in_ptr, uint32_t* __restrict__ n_out_ptr,
+        uint32_t* __restrict__ work, const PtHit* __restrict__ hits,
+        const float4* __restrict__ q0, const float4* __restrict__ q1, const float4* __restrict__ q2, const float4* __restrict__ q3,
+        float4* __restrict__ o0, float4* __restrict__ o1, float4* __restrict__ o2, float4* __restrict__ o3,
+        float4* __restrict__ path_result)
+{
+    const uint32_t n = *n_in_ptr;
+    const uint32_t lane = threadIdx.x & 63;
+    const float PI_F = 3.14159265f;
+    for (;;) {
+        const uint32_t base = wave_fetch(work);
+        if (base >= n) break;
+        const uint32_t i = base + lane;
+        bool alive = false;
+        float4 no, nd, nw, nh;
+        if (i < n) {
+            const PtHit h = hits[i];
+            const uint32_t seed_in = __float_as_uint(q0[i].w);
+            const uint32_t path = __float_as_uint(q1[i].w);
+            const float4 cw = q2[i];
+            float4 hv = q3[i];
+            if (h.instance == 0xFFFFFFFFu) {
+                // miss.rmiss:10-20
+                const float e = depth == 0 ? 1.0f * 0.8f : 0.01f;
+                hv.x = PT_FMA(e, cw.x, hv.x); hv.y = PT_FMA(e, cw.y, hv.y); hv.z = PT_FMA(e, cw.z, hv.z);
+                path_result[path] = hv;
+            } else {
+                // closest_hit.rchit:57-60
+                const PtDevShadeInstance& I = tb.shade_inst[h.instance];
+                const uint32_t custom = __float_as_uint(I.meta.x);
+                const PtGeometryNode gn = tb.geometry_nodes[tb.blas_instances[custom].firstGeometryIndex];
+                const PtMaterial* m = &tb.materials[gn.materialIndex];
+                const PtVertex* vertices = (const PtVertex*)(uintptr_t)gn.vertexBufferDeviceAddress;
+                const uint32_t* indices = (const uint32_t*)(uintptr_t)gn.indexBufferDeviceAddress;
+                const PtVertex A = vertices[indices[3 * (size_t)h.primitive + 0]];
+                const PtVertex B = vertices[indices[3 * (size_t)h.primitive + 1]];
+                const PtVertex C = vertices[indices[3 * (size_t)h.primitive + 2]];
+                const float b0 = 1.0f - h.u - h.v, b1 = h.u, b2 = h.v;
+#define PT_MIX3(x, y, z) PT_FMA((z), b2, PT_FMA((y), b1, (x) * b0))
+                float px = PT_MIX3(A.px, B.px, C.px), py = PT_MIX3(A.py, B.py, C.py), pz = PT_MIX3(A.pz, B.pz, C.pz);
+                float nx = PT_MIX3(A.nx, B.nx, C.nx), ny = PT_MIX3(A.ny, B.ny, C.ny), nz = PT_MIX3(A.nz, B.nz, C.nz);
+                float tu = PT_MIX3(A.tu, B.tu, C.tu), tv = PT_MIX3(A.tv, B.tv, C.tv);
+#undef PT_MIX3
+                pt_normalize(nx, ny, nz);
+                // :62-63
+                const float4 m0 = I.o2w[0], m1 = I.o2w[1], m2 = I.o2w[2];
+                float wx = PT_FMA(m0.x, px, PT_FMA(m0.y, py, PT_FMA(m0.z, pz, m0.w)));
+                float wy = PT_FMA(m1.x, px, PT_FMA(m1.y, py, PT_FMA(m1.z, pz, m1.w)));
+                float wz = PT_FMA(m2.x, px, PT_FMA(m2.y, py, PT_FMA(m2.z, pz, m2.w)));
+                const float4 w0 = I.w2o[0], w1 = I.w2o[1], w2 = I.w2o[2];
+                float Nx = PT_FMA(w0.x, nx, PT_FMA(w1.x, ny, w2.x * nz));
+                float Ny = PT_FMA(w0.y, nx, PT_FMA(w1.y, ny, w2.y * nz));
+                float Nz = PT_FMA(w0.z, nx, PT_FMA(w1.z, ny, w2.z * nz));
+                pt_normalize(Nx, Ny, Nz);
+                // CreateCoordinateSystem, sampling.glsl:53-65
+                float Tx, Ty, Tz;
+                if (fabsf(Nx) > fabsf(Ny)) {
+                    float inv = 1.0f / sqrtf(PT_FMA(Nz, Nz, Nx * Nx));
+                    Tx = Nz * inv; Ty = 0.0f; Tz = -Nx * inv;
+                } else {
+                    float inv = 1.0f / sqrtf(PT_FMA(Nz, Nz, Ny * Ny));
+                    Tx = 0.0f; Ty = -Nz * inv; Tz = Ny * inv;
+                }
+                float Bx = PT_FMA(Ny, Tz, -(Nz * Ty));
+                float By = PT_FMA(Nz, Tx, -(Nx * Tz));
+                float Bz = PT_FMA(Nx, Ty, -(Ny * Tx));
+                // SamplingHemisphere, sampling.glsl:38-50
+                uint32_t seed = seed_in;
+                float r1 = pt_random(seed);
+                float r2 = pt_random(seed);
+                float sq = sqrtf(r1);
+                float sn, cs;
+                pt_sincos(6.28318548f * r2, sn, cs);
+                float lx = cs * sq, ly = sn * sq, lz = sqrtf(1.0f - r1);
+                float Dx = PT_FMA(lz, Nx, PT_FMA(ly, Bx, lx * Tx));
+                float Dy = PT_FMA(lz, Ny, PT_FMA(ly, By, lx * Ty));
+                float Dz = PT_FMA(lz, Nz, PT_FMA(ly, Bz, lx * Tz));
+                // :71-85
+                float cosTheta = PT_FMA(Dz, Nz, PT_FMA(Dy, Ny, Dx * Nx));
+                float pdf = cosTheta / PI_F;
+                float ar = m->albedoFactor[0], ag = m->albedoFactor[1], ab = m->albedoFactor[2];
+                if (m->useAlbedoMap) {
+                    float tr, tg, tbb;
+                    pt_texture_rgb(tb.textures[m->albedoMapIndex], tu, tv, tr, tg, tbb);
+                    ar = ar * tr; ag = ag * tg; ab = ab * tbb;
+                }
+                float wr = (ar / PI_F) * cosTheta / pdf, wg = (ag / PI_F) * cosTheta / pdf, wb = (ab / PI_F) * cosTheta / pdf;
+                // ray_gen.rgen:67-68
+                hv.x = PT_FMA(m->emissiveFactor[0], cw.x, hv.x);
+                hv.y = PT_FMA(m->emissiveFactor[1], cw.y, hv.y);
+                hv.z = PT_FMA(m->emissiveFactor[2], cw.z, hv.z);
+                if (depth + 1 < max_depth) {
+                    alive = true;
+                    no = make_float4(wx, wy, wz, __uint_as_float(seed));
+                    nd = make_float4(Dx, Dy, Dz, __uint_as_float(path));
+                    nw = make_float4(cw.x * wr, cw.y * wg, cw.z * wb, 0.0f);
+                    nh = hv;
+                } else {
+                    path_result[path] = hv;
+                }
+            }
+        }
+        // wave-level compaction: one atomic per wave, lanes take consecutive slots
+        const unsigned long long bal = __ballot(alive);
+        const uint32_t cnt = __popcll(bal);
+        if (cnt) {
+            uint32_t slot0 = 0;
+            if (lane == 0) slot0 = atomicAdd(n_out_ptr, cnt);
+            slot0 = __builtin_amdgcn_readfirstlane(slot0);
+            if (alive) {
+                const uint32_t slot = slot0 + __popcll(bal & ((1ull << lane) - 1ull));
+                o0[slot] = no; o1[slot] = nd; o2[slot] = nw; o3[slot] = nh;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// ray_gen.rgen:71-87 for the pixels of one chunk
+__global__ void __launch_bounds__(kBlock)
+k_accumulate(uint32_t n_pixels, uint32_t pixel0, uint32_t spp, uint32_t frame, uint32_t mode,
+             const float4* __restrict__ path_result, float* __restrict__ frame_result, void* __restrict__ accum)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pixels) return;
+    float r = 0.0f, g = 0.0f, b = 0.0f;
+    for (uint32_t s = 0; s < spp; ++s) {
+        const float4 hv = path_result[(size_t)p * spp + s];
+        r = PT_FMA(hv.x, 2.5f, r); g = PT_FMA(hv.y, 2.5f, g); b = PT_FMA(hv.z, 2.5f, b);
+    }
+    const float fs = (float)spp;
+    r = r / fs; g = g / fs; b = b / fs;
+    const size_t pix = (size_t)pixel0 + p;
+    frame_result[3 * pix + 0] = r; frame_result[3 * pix + 1] = g; frame_result[3 * pix + 2] = b;
+    if (mode == PT_ACCUM_SUM_F32) {
+        float4* a = (float4*)accum;
+        float4 v = a[pix];
+        v.x += r; v.y += g; v.z += b; v.w += 1.0f;
+        a[pix] = v;
+    } else if (mode == PT_ACCUM_MEAN_F32) {
+        float4* a = (float4*)accum;
+        float4 v = a[pix];
+        const float w = 1.0f / (float)(frame + 1);
+        if (frame > 0) { v.x = PT_FMA(r, w, v.x * (1.0f - w)); v.y = PT_FMA(g, w, v.y * (1.0f - w)); v.z = PT_FMA(b, w, v.z * (1.0f - w)); }
+        else { v.x = r; v.y = g; v.z = b; }
+        v.w = 1.0f;
+        a[pix] = v;
+    } else {
+        uchar4* a = (uchar4*)accum;
+        uchar4 v = a[pix];
+        const float w = 1.0f / (float)(frame + 1);
+        float c[3] = { r, g, b };
+        float old[3] = { (float)v.x / 255.0f, (float)v.y / 255.0f, (float)v.z / 255.0f };
+        unsigned char q[3];
+        for (int k = 0; k < 3; ++k) {
+            float x = frame > 0 ? PT_FMA(c[k], w, old[k] * (1.0f - w)) : c[k];
+            x = x > 0.0f ? (x < 1.0f ? x : 1.0f) : 0.0f;
+            q[k] = (unsigned char)(int)rintf(x * 255.0f);
+        }
+        a[pix] = make_uchar4(q[0], q[1], q[2], 255);
+    }
+}
+
+__global__ void k_stats(const uint32_t* __restrict__ counters, uint32_t max_depth, uint32_t n_paths, uint64_t* __restrict__ stats)
+{
+    uint32_t d = threadIdx.x;
+    if (d < max_depth) stats[d] += counters[d];
+    if (d == 0) stats[PT_MAX_DEPTH] += n_paths;
+}
+
+__global__ void k_resolve(uint32_t n, const float4* __restrict__ sum, uchar4* __restrict__ out, int bgra)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 s = sum[i];
+    float c[3] = { s.x / s.w, s.y / s.w, s.z / s.w };
+    unsigned char q[3];
+    for (int k = 0; k < 3; ++k) {
+        float x = c[k] > 0.0f ? (c[k] < 1.0f ? c[k] : 1.0f) : 0.0f;
+        q[k] = (unsigned char)(int)rintf(x * 255.0f);
+    }
+    out[i] = bgra ? make_uchar4(q[2], q[1], q[0], 255) : make_uchar4(q[0], q[1], q[2], 255);
+}
+
+// ------------------------------------------------------------------------------------------------
+int persistent_blocks(PtContext* ctx, const void* kernel)
+{
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+    if (per_cu > 8) per_cu = 8;
+    return ctx->num_cus * per_cu;
+}
+
+struct Workspace {
+    static int ensure(PtContext* ctx, uint64_t paths, uint64_t pixels)
+    {
+        PtWorkspace& w = ctx->ws;
+        if (!w.counters) {
+            PT_HIP_CHECK(hipMalloc((void**)&w.counters, sizeof(uint32_t) * 3 * kCounterStride));
+            PT_HIP_CHECK(hipMalloc((void**)&w.stats, sizeof(uint64_t) * (PT_MAX_DEPTH + 1)));
+            PT_HIP_CHECK(hipMemset(w.stats, 0, sizeof(uint64_t) * (PT_MAX_DEPTH + 1)));
+            PT_HIP_CHECK(hipMalloc((void**)&w.cam, sizeof(float) * 32));
+            w.spill_threads = (uint64_t)ctx->num_cus * 8 * kBlock;
+            PT_HIP_CHECK(hipMalloc((void**)&w.spill, sizeof(int) * PT_SPILL_STACK * w.spill_threads));
+        }
+        if (paths > w.paths_cap) {
+            for (int a = 0; a < 2; ++a) for (int k = 0; k < 4; ++k) { (void)hipFree(w.q[a][k]); w.q[a][k] = nullptr; }
+            (void)hipFree(w.hits); (void)hipFree(w.path_result); w.hits = nullptr; w.path_result = nullptr;
+            w.paths_cap = 0;
+            for (int a = 0; a < 2; ++a) for (int k = 0; k < 4; ++k) PT_HIP_CHECK(hipMalloc((void**)&w.q[a][k], sizeof(float4) * paths));
+            PT_HIP_CHECK(hipMalloc((void**)&w.hits, sizeof(PtHit) * paths));
+            PT_HIP_CHECK(hipMalloc((void**)&w.path_result, sizeof(float4) * paths));
+            w.paths_cap = paths;
+        }
+        if (pixels > w.frame_pixels_cap) {
+            (void)hipFree(w.frame_result); w.frame_result = nullptr; w.frame_pixels_cap = 0;
+            PT_HIP_CHECK(hipMalloc((void**)&w.frame_result, sizeof(float) * 3 * pixels));
+            w.frame_pixels_cap = pixels;
+        }
+        return PT_OK;
+    }
+};
+
+PtTlasView view_of(const PtTlas* t)
+{
+    PtTlasView v;
+    v.nodes = (const float4*)t->nodes; v.leaf_inst = t->leaf_inst; v.inst = t->inst;
+    return v;
+}
+
+} // namespace
+
+extern "C" {
+
+int pt_intersect(PtContext* ctx, const PtTlas* tlas, uint32_t n, const float* origins_dev, const float* dirs_dev,
+                 float tmin, float tmax, PtHit* hits_dev, float* t_dev)
+{
+    PT_REQUIRE(ctx && tlas && origins_dev && dirs_dev && hits_dev, "null argument");
+    PT_REQUIRE(tlas->ctx == ctx, "the TLAS belongs to another context");
+    if (n == 0) return PT_OK;
+    PT_HIP_CHECK(hipSetDevice(ctx->device));
+    int rc = Workspace::ensure(ctx, n, 0);
+    if (rc) return rc;
+    PtWorkspace& w = ctx->ws;
+    hipStream_t st = ctx->stream;
+    PT_HIP_CHECK(hipMemsetAsync(w.counters, 0, sizeof(uint32_t) * 3 * kCounterStride, st));
+    k_pack_rays<<<(n + kBlock - 1) / kBlock, kBlock, 0, st>>>(n, origins_dev, dirs_dev, w.q[0][0], w.q[0][1], w.counters);
+    int blocks = persistent_blocks(ctx, (const void*)k_intersect);
+    k_intersect<<<blocks, kBlock, 0, st>>>(view_of(tlas), w.counters, w.counters + kCounterStride, w.q[0][0], w.q[0][1],
+                                           tmin, tmax, hits_dev, t_dev, w.spill);
+    PT_HIP_CHECK(hipGetLastError());
+    return PT_OK;
+}
+
+int pt_trace(PtContext* ctx, const PtTlas* tlas, const float camera[32], uint32_t width, uint32_t height,
+             uint32_t frame, uint32_t spp, uint32_t max_depth, uint32_t seed_mode, uint32_t accum_mode, void* accum_dev)
+{
+    PT_REQUIRE(ctx && tlas && camera && accum_dev, "null argument");
+    PT_REQUIRE(tlas->ctx == ctx, "the TLAS belongs to another context");
+    PT_REQUIRE(width > 0 && height > 0 && (uint64_t)width * height < (1ull << 31), "bad image size");
+    PT_REQUIRE(spp > 0 && spp <= 65536, "samples_per_frame must be in [1, 65536]");
+    PT_REQUIRE(max_depth > 0 && max_depth < PT_MAX_DEPTH, "max_depth must be in [1, 63]");
+    PT_REQUIRE(seed_mode <= PT_SEED_CLOCK && accum_mode <= PT_ACCUM_MEAN_UNORM8, "bad mode");
+    PT_REQUIRE(ctx->materials && ctx->geometry_nodes && ctx->blas_instances, "pt_scene_set_tables has not been called");
+    PT_REQUIRE(ctx->n_blas_instances >= tlas->n, "fewer BLASInstance records than TLAS instances");
+    PT_HIP_CHECK(hipSetDevice(ctx->device));
+    const uint64_t n_pixels = (uint64_t)width * height;
+    uint64_t chunk_pixels = ctx->max_paths / spp;
+    if (chunk_pixels < 1) chunk_pixels = 1;
+    if (chunk_pixels > n_pixels) chunk_pixels = n_pixels;
+    PT_REQUIRE(chunk_pixels * spp < (1ull << 32), "max_paths too large");
+    int rc = Workspace::ensure(ctx, chunk_pixels * spp, n_pixels);
+    if (rc) return rc;
+    PtWorkspace& w = ctx->ws;
+    hipStream_t st = ctx->stream;
+    PT_HIP_CHECK(hipMemcpyAsync(w.cam, camera, sizeof(float) * 32, hipMemcpyHostToDevice, st));
+    PtTables tb;
+    tb.materials = ctx->materials; tb.geometry_nodes = ctx->geometry_nodes; tb.blas_instances = ctx->blas_instances;
+    tb.textures = ctx->textures; tb.shade_inst = tlas->shade_inst;
+    const PtTlasView tv = view_of(tlas);
+    const int blocks_i = persistent_blocks(ctx, (const void*)k_intersect);
+    const int blocks_s = persistent_blocks(ctx, (const void*)k_shade);
+    for (uint64_t p0 = 0; p0 < n_pixels; p0 += chunk_pixels) {
+        const uint32_t np = (uint32_t)((n_pixels - p0) < chunk_pixels ? (n_pixels - p0) : chunk_pixels);
+        const uint32_t n_paths = np * spp;
+        PT_HIP_CHECK(hipMemsetAsync(w.counters, 0, sizeof(uint32_t) * 3 * kCounterStride, st));
+        k_generate<<<(n_paths + kBlock - 1) / kBlock, kBlock, 0, st>>>(n_paths, (uint32_t)p0, spp, width, height, frame, seed_mode, w.cam,
+                                                                      w.q[0][0], w.q[0][1], w.q[0][2], w.q[0][3], w.counters);
+        for (uint32_t d = 0; d < max_depth; ++d) {
+            const int a = d & 1, b = a ^ 1;
+            k_intersect<<<blocks_i, kBlock, 0, st>>>(tv, w.counters + d, w.counters + kCounterStride + d, w.q[a][0], w.q[a][1],
+                                                     0.001f, 10000.0f, w.hits, nullptr, w.spill);
+            k_shade<<<blocks_s, kBlock, 0, st>>>(tb, d, max_depth, w.counters + d, w.counters + d + 1, w.counters + 2 * kCounterStride + d, w.hits,
+                                                 w.q[a][0], w.q[a][1], w.q[a][2], w.q[a][3], w.q[b][0], w.q[b][1], w.q[b][2], w.q[b][3],
+                                                 w.path_result);
+        }
+        k_accumulate<<<(np + kBlock - 1) / kBlock, kBlock, 0, st>>>(np, (uint32_t)p0, spp, frame, accum_mode, w.path_result, w.frame_result, accum_dev);
+        k_stats<<<1, 64, 0, st>>>(w.counters, max_depth, n_paths, w.stats);
+    }
+    PT_HIP_CHECK(hipGetLastError());
+    ctx->last_w = width; ctx->last_h = height;
+    return PT_OK;
+}
+
+int pt_trace_last_result(PtContext* ctx, float* result_host)
+{
+    PT_REQUIRE(ctx && result_host, "null argument");
+    PT_REQUIRE(ctx->last_w && ctx->ws.frame_result, "no frame has been traced");
+    PT_HIP_CHECK(hipSetDevice(ctx->device));
+    PT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    PT_HIP_CHECK(hipMemcpy(result_host, ctx->ws.frame_result, sizeof(float) * 3 * (size_t)ctx->last_w * ctx->last_h, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+int pt_trace_stats(PtContext* ctx, PtTraceStats* out)
+{
+    PT_REQUIRE(ctx && out, "null argument");
+    memset(out, 0, sizeof *out);
+    if (!ctx->ws.stats) return PT_OK;
+    PT_HIP_CHECK(hipSetDevice(ctx->device));
+    PT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    uint64_t h[PT_MAX_DEPTH + 1];
+    PT_HIP_CHECK(hipMemcpy(h, ctx->ws.stats, sizeof h, hipMemcpyDeviceToHost));
+    for (int d = 0; d < PT_MAX_DEPTH; ++d) { out->rays_per_depth[d] = h[d]; out->rays += h[d]; }
+    out->paths = h[PT_MAX_DEPTH];
+    return PT_OK;
+}
+
+int pt_trace_stats_reset(PtContext* ctx)
+{
+    PT_REQUIRE(ctx, "null argument");
+    if (!ctx->ws.stats) return PT_OK;
+    PT_HIP_CHECK(hipSetDevice(ctx->device));
+    PT_HIP_CHECK(hipMemsetAsync(ctx->ws.stats, 0, sizeof(uint64_t) * (PT_MAX_DEPTH + 1), ctx->stream));
+    return PT_OK;
+}
+
+int pt_accum_resolve(PtContext* ctx, const float* accum_sum_dev, uint32_t n_pixels, uint8_t* rgba8_dev, int bgra)
+{
+    PT_REQUIRE(ctx && accum_sum_dev && rgba8_dev, "null argument");
+    if (n_pixels == 0) return PT_OK;
+    PT_HIP_CHECK(hipSetDevice(ctx->device));
+    k_resolve<<<(n_pixels + kBlock - 1) / kBlock, kBlock, 0, ctx->stream>>>(n_pixels, (const float4*)accum_sum_dev, (uchar4*)rgba8_dev, bgra);
+    PT_HIP_CHECK(hipGetLastError());
+    return PT_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,195 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on identical inputs.
+Integer results (BVH topology, hit ids) and, because sin/cos and every operation order are pinned,
+all float results as well are compared bit for bit."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle(scene):
+    import oracle as O
+    return O.OracleScene(scene)
+
+
+def _renderer(scene, w, h, **kw):
+    from pt_amd import hip
+    return hip.Renderer(scene, w, h, **kw)
+
+
+def _random_rays(n, seed, lo=-2.5, hi=3.0):
+    rng = np.random.default_rng(seed)
+    o = rng.uniform(lo, hi, size=(n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return o, d.astype(np.float32)
+
+
+def _float_eq(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return a.shape == b.shape and bool(np.all((a == b) | (np.isnan(a) & np.isnan(b))))
+
+
+@pytest.mark.parametrize("name", ["cornell", "cube", "soup", "dragon"])
+def test_bvh_topology_bit_exact(name, request):
+    scene = request.getfixturevalue(name)
+    orc = _oracle(scene)
+    r = _renderer(scene, 8, 8)
+    try:
+        for i, (ob, gb) in enumerate(zip(orc.blases, r.blases)):
+            nodes, prims, keys = gb.download()
+            assert np.array_equal(keys, ob.sorted_keys()), f"blas {i}: sorted Morton keys differ"
+            assert np.array_equal(prims, ob.leaf_prims()), f"blas {i}: primitive order differs"
+            on = ob.nodes()
+            assert len(nodes) == len(on), f"blas {i}: node count {len(nodes)} vs {len(on)}"
+            assert np.array_equal(nodes["c0"], on["c0"]) and np.array_equal(nodes["c1"], on["c1"]), f"blas {i}: child references differ"
+            for f in ("lo0", "hi0", "lo1", "hi1"):
+                assert _float_eq(nodes[f], on[f]), f"blas {i}: boxes differ in {f}"
+            info = gb.info()
+            lo, hi = ob.root_box()
+            assert _float_eq(info["root_lo"], lo) and _float_eq(info["root_hi"], hi)
+            assert float(info["delta"]) == ob.delta()
+        nodes, leaf, boxes, w2o = r.tlas.download()
+        on = orc.tlas.nodes()
+        assert np.array_equal(leaf, orc.tlas.leaf_instances())
+        assert len(nodes) == len(on)
+        assert np.array_equal(nodes["c0"], on["c0"]) and np.array_equal(nodes["c1"], on["c1"])
+        for f in ("lo0", "hi0", "lo1", "hi1"):
+            assert _float_eq(nodes[f], on[f])
+        for i in range(orc.tlas.n):
+            lo, hi = orc.tlas.instance_box(i)
+            assert _float_eq(boxes[i, :3], lo) and _float_eq(boxes[i, 3:], hi)
+            assert _float_eq(w2o[i], orc.tlas.instance_w2o(i))
+    finally:
+        r.close()
+
+
+@pytest.mark.parametrize("name,n", [("cornell", 200000), ("cube", 100000), ("soup", 100000), ("dragon", 100000)])
+def test_intersect_hit_ids_bit_exact(name, n, request):
+    scene = request.getfixturevalue(name)
+    orc = _oracle(scene)
+    r = _renderer(scene, 8, 8)
+    try:
+        o, d = _random_rays(n, seed=11)
+        hits, t = r.intersect(o, d)
+        oh, ot = orc.tlas.intersect(o, d, use_bvh=True)
+        assert np.array_equal(hits["instance"], oh["instance"])
+        assert np.array_equal(hits["primitive"], oh["primitive"])
+        assert _float_eq(hits["u"], oh["u"]) and _float_eq(hits["v"], oh["v"]) and _float_eq(t, ot)
+        assert (hits["instance"] != 0xFFFFFFFF).mean() > 0.02
+        # brute force (no BVH at all) on a subset
+        m = 3000 if name == "dragon" else 20000
+        bh, bt = orc.tlas.intersect(o[:m], d[:m], use_bvh=False)
+        assert np.array_equal(hits[:m], bh) and _float_eq(t[:m], bt)
+    finally:
+        r.close()
+
+
+@pytest.mark.parametrize("name,w,h,spp", [("cornell", 128, 128, 16), ("cube", 96, 64, 8), ("dragon", 160, 90, 4), ("soup", 64, 64, 4)])
+def test_render_frame_bit_exact(name, w, h, spp, request):
+    from pt_amd import camera
+    scene = request.getfixturevalue(name)
+    orc = _oracle(scene)
+    r = _renderer(scene, w, h)
+    try:
+        cam = camera.camera_uniform(w, h)
+        for frame in (0, 1):
+            r.render(spp=spp, max_depth=10, frame=frame)
+            got = r.last_result()
+            want, st = orc.render_frame(cam, w, h, frame=frame, spp=spp, threads=8)
+            assert _float_eq(got, want), f"frame {frame}: {np.sum(got != want)} of {got.size} values differ"
+        stats = r.stats()
+        assert int(stats["paths"]) == 2 * w * h * spp
+    finally:
+        r.close()
+
+
+def test_ray_counts_match_oracle(cornell):
+    from pt_amd import camera
+    orc = _oracle(cornell)
+    w = h = 64
+    r = _renderer(cornell, w, h)
+    try:
+        r.render(spp=8, frame=0)
+        want, st = orc.render_frame(camera.camera_uniform(w, h), w, h, frame=0, spp=8, threads=4)
+        s = r.stats()
+        assert int(s["rays"]) == int(st["rays"])
+        assert int(s["rays_per_depth"][0]) == w * h * 8
+    finally:
+        r.close()
+
+
+def test_chunked_frame_equals_single_chunk(cornell):
+    w = h = 64
+    a = _renderer(cornell, w, h)
+    b = _renderer(cornell, w, h)
+    try:
+        b.ctx.set_max_paths(5000)   # forces several pixel chunks, one of them partial
+        a.render(spp=4, frame=3)
+        b.render(spp=4, frame=3)
+        assert _float_eq(a.last_result(), b.last_result())
+        assert _float_eq(a.accum_host(), b.accum_host())
+    finally:
+        a.close()
+        b.close()
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_accumulation_modes(mode, cornell):
+    import oracle as O
+    from pt_amd import camera
+    w = h = 48
+    orc = _oracle(cornell)
+    r = _renderer(cornell, w, h)
+    try:
+        cam = camera.camera_uniform(w, h)
+        acc = np.zeros((w * h, 4), dtype=np.uint8 if mode == 2 else np.float32)
+        for frame in range(3):
+            r.render(spp=4, frame=frame, accum_mode=mode)
+            res, _ = orc.render_frame(cam, w, h, frame=frame, spp=4, threads=4)
+            O.accumulate(mode, frame, res, acc)
+        got = r.accum_host().reshape(w * h, 4)
+        if mode == 2:
+            assert np.array_equal(got, acc)
+        else:
+            assert _float_eq(got, acc)
+        if mode == 0:
+            assert np.array_equal(r.resolve().reshape(-1, 4), O.resolve(acc))
+            bgra = r.resolve(bgra=True).reshape(-1, 4)
+            assert np.array_equal(bgra[:, [2, 1, 0, 3]], O.resolve(acc))
+    finally:
+        r.close()
+
+
+def test_full_size_properties_1080p(dragon):
+    """BASELINE size (1080p): properties that need no oracle run -- every path accounted for,
+    one primary ray per path, monotone ray counts per bounce, finite non-negative radiance,
+    and sample-count linearity of the float sum."""
+    w, h, spp = 1920, 1080, 2
+    r = _renderer(dragon, w, h)
+    try:
+        r.render(spp=spp, frame=0)
+        s = r.stats()
+        assert int(s["paths"]) == w * h * spp
+        assert int(s["rays_per_depth"][0]) == w * h * spp
+        rp = s["rays_per_depth"][:10].astype(np.int64)
+        assert np.all(np.diff(rp) <= 0)
+        res = r.last_result()
+        assert np.isfinite(res).all() and (res >= 0).all()
+        r.render(spp=spp, frame=1)
+        acc = r.accum_host()
+        assert np.all(acc[..., 3] == 2.0)
+    finally:
+        r.close()
+
+
+def test_errors_are_reported(cornell):
+    from pt_amd import hip
+    r = _renderer(cornell, 16, 16)
+    try:
+        with pytest.raises(hip.PtError):
+            r.render(spp=70000)
+        with pytest.raises(hip.PtError):
+            r.render(spp=4, max_depth=64)
+    finally:
+        r.close()
