@@ -165,6 +165,18 @@ int pt_trace(PtContext* ctx, const PtTlas* tlas, const float camera[32], uint32_
 int pt_trace_last_result(PtContext* ctx, float* result_host);
 int pt_trace_stats(PtContext* ctx, PtTraceStats* out);       /* synchronous */
 int pt_trace_stats_reset(PtContext* ctx);
+/* Timing of the intersect kernel with HIP events on the context's stream (off by default).
+ * While enabled, every intersect launch of pt_trace is bracketed by an event pair;
+ * pt_trace_profile waits for the stream, adds up the pairs recorded since the last call and
+ * returns them.  Has no counterpart in the reference (it has no timers). */
+typedef struct PtTraceProfile {
+    uint64_t intersect_launches;
+    uint64_t intersect_rays;
+    double   intersect_ms;
+} PtTraceProfile;
+int pt_ctx_set_profiling(PtContext* ctx, int enabled);
+int pt_trace_profile(PtContext* ctx, PtTraceProfile* out);
+
 /* Upper bound on paths resident at once (default 1<<25); a frame is rendered in pixel chunks. */
 int pt_ctx_set_max_paths(PtContext* ctx, uint64_t max_paths);
 

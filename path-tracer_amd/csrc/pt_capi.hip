@@ -59,6 +59,7 @@ int pt_ctx_destroy(PtContext* c)
     (void)hipFree(w.hits); (void)hipFree(w.path_result); (void)hipFree(w.frame_result);
     (void)hipFree(w.counters); (void)hipFree(w.stats); (void)hipFree(w.cam); (void)hipFree(w.spill);
     (void)hipFree(c->materials); (void)hipFree(c->geometry_nodes); (void)hipFree(c->blas_instances); (void)hipFree(c->textures);
+    for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return PT_OK;

@@ -90,6 +90,12 @@ struct PtContext {
     PtTextureDesc* textures = nullptr; uint32_t n_textures = 0;
     PtWorkspace ws;
     uint32_t last_w = 0, last_h = 0;
+    // intersect-kernel timing (pt_ctx_set_profiling)
+    bool profiling = false;
+    std::vector<hipEvent_t> ev_pool;           // pairs: start, stop
+    size_t ev_used = 0;
+    std::vector<uint32_t> ev_depth;            // depth of each recorded pair
+    uint64_t stats_mark[PT_MAX_DEPTH] = {};    // rays_per_depth at the last pt_trace_profile
 };
 
 // pt_build.hip

@@ -426,8 +426,20 @@ int pt_trace(PtContext* ctx, const PtTlas* tlas, const float camera[32], uint32_
                                                                       w.q[0][0], w.q[0][1], w.q[0][2], w.q[0][3], w.counters);
         for (uint32_t d = 0; d < max_depth; ++d) {
             const int a = d & 1, b = a ^ 1;
+            hipEvent_t ev_stop = nullptr;
+            if (ctx->profiling) {
+                if (ctx->ev_used + 2 > ctx->ev_pool.size()) {
+                    hipEvent_t e0, e1;
+                    PT_HIP_CHECK(hipEventCreate(&e0)); PT_HIP_CHECK(hipEventCreate(&e1));
+                    ctx->ev_pool.push_back(e0); ctx->ev_pool.push_back(e1);
+                }
+                PT_HIP_CHECK(hipEventRecord(ctx->ev_pool[ctx->ev_used], st));
+                ev_stop = ctx->ev_pool[ctx->ev_used + 1];
+                ctx->ev_used += 2;
+            }
             k_intersect<<<blocks_i, kBlock, 0, st>>>(tv, w.counters + d, w.counters + kCounterStride + d, w.q[a][0], w.q[a][1],
                                                      0.001f, 10000.0f, w.hits, nullptr, w.spill);
+            if (ev_stop) PT_HIP_CHECK(hipEventRecord(ev_stop, st));
             k_shade<<<blocks_s, kBlock, 0, st>>>(tb, d, max_depth, w.counters + d, w.counters + d + 1, w.counters + 2 * kCounterStride + d, w.hits,
                                                  w.q[a][0], w.q[a][1], w.q[a][2], w.q[a][3], w.q[b][0], w.q[b][1], w.q[b][2], w.q[b][3],
                                                  w.path_result);
@@ -464,12 +476,41 @@ int pt_trace_stats(PtContext* ctx, PtTraceStats* out)
     return PT_OK;
 }
 
+int pt_ctx_set_profiling(PtContext* ctx, int enabled)
+{
+    PT_REQUIRE(ctx, "null argument");
+    ctx->profiling = enabled != 0;
+    return PT_OK;
+}
+
+int pt_trace_profile(PtContext* ctx, PtTraceProfile* out)
+{
+    PT_REQUIRE(ctx && out, "null argument");
+    memset(out, 0, sizeof *out);
+    PT_HIP_CHECK(hipSetDevice(ctx->device));
+    PT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    for (size_t k = 0; k + 1 < ctx->ev_used; k += 2) {
+        float ms = 0.0f;
+        PT_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev_pool[k], ctx->ev_pool[k + 1]));
+        out->intersect_ms += ms;
+        out->intersect_launches++;
+    }
+    ctx->ev_used = 0;
+    if (ctx->ws.stats) {
+        uint64_t h[PT_MAX_DEPTH + 1];
+        PT_HIP_CHECK(hipMemcpy(h, ctx->ws.stats, sizeof h, hipMemcpyDeviceToHost));
+        for (int d = 0; d < PT_MAX_DEPTH; ++d) { out->intersect_rays += h[d] - ctx->stats_mark[d]; ctx->stats_mark[d] = h[d]; }
+    }
+    return PT_OK;
+}
+
 int pt_trace_stats_reset(PtContext* ctx)
 {
     PT_REQUIRE(ctx, "null argument");
     if (!ctx->ws.stats) return PT_OK;
     PT_HIP_CHECK(hipSetDevice(ctx->device));
     PT_HIP_CHECK(hipMemsetAsync(ctx->ws.stats, 0, sizeof(uint64_t) * (PT_MAX_DEPTH + 1), ctx->stream));
+    memset(ctx->stats_mark, 0, sizeof ctx->stats_mark);
     return PT_OK;
 }
 

@@ -22,6 +22,7 @@ ACCUM_SUM_F32, ACCUM_MEAN_F32, ACCUM_MEAN_UNORM8 = 0, 1, 2
 
 AS_INFO = np.dtype([("node_count", "<u4"), ("prim_count", "<u4"), ("root_lo", "<f4", 3), ("root_hi", "<f4", 3),
                     ("delta", "<f4"), ("build_ms", "<f4")])
+TRACE_PROFILE = np.dtype([("intersect_launches", "<u8"), ("intersect_rays", "<u8"), ("intersect_ms", "<f8")])
 TRACE_STATS = np.dtype([("rays_per_depth", "<u8", PT_MAX_DEPTH), ("rays", "<u8"), ("paths", "<u8")])
 
 # every symbol include/pt_hip.h declares: (restype, argtypes)
@@ -49,6 +50,8 @@ SIGNATURES = {
     "pt_trace_stats": (_i, [_vp, _vp]),
     "pt_trace_stats_reset": (_i, [_vp]),
     "pt_ctx_set_max_paths": (_i, [_vp, _u64]),
+    "pt_ctx_set_profiling": (_i, [_vp, _i]),
+    "pt_trace_profile": (_i, [_vp, _vp]),
     "pt_accum_resolve": (_i, [_vp, _vp, _u32, _vp, _i]),
 }
 
@@ -281,6 +284,14 @@ class Renderer:
     def stats(self):
         out = np.zeros(1, dtype=TRACE_STATS)
         _check(self.ctx.lib.pt_trace_stats(self.ctx.h, _p(out)))
+        return out[0]
+
+    def set_profiling(self, enabled):
+        _check(self.ctx.lib.pt_ctx_set_profiling(self.ctx.h, int(enabled)))
+
+    def profile(self):
+        out = np.zeros(1, dtype=TRACE_PROFILE)
+        _check(self.ctx.lib.pt_trace_profile(self.ctx.h, _p(out)))
         return out[0]
 
     def reset_stats(self):
