@@ -605,7 +605,7 @@ int pt_tlas_build(PtContext* ctx, const PtInstance* instances, uint32_t n, PtTla
     t->ctx = ctx; t->n = n; t->nodes = nullptr; t->leaf_inst = nullptr; t->inst = nullptr; t->shade_inst = nullptr;
     t->host_boxes.resize((size_t)n * 6); t->host_w2o.resize((size_t)n * 12);
     std::vector<PtDevInstance> di(n);
-    std::vector<PtDevShadeInstance> ds(n);
+    t->host_o2w.resize((size_t)n * 12); t->host_custom.resize(n); t->shade_version = 0;
     const float inf = std::numeric_limits<float>::infinity();
     for (int k = 0; k < 3; ++k) { t->root_lo[k] = inf; t->root_hi[k] = -inf; }
     for (uint32_t i = 0; i < n; ++i) {
@@ -640,10 +640,9 @@ int pt_tlas_build(PtContext* ctx, const PtInstance* instances, uint32_t n, PtTla
         float customf; memcpy(&customf, &custom, 4);
         for (int r = 0; r < 3; ++r) {
             di[i].q[r] = make_float4(w2o[4 * r], w2o[4 * r + 1], w2o[4 * r + 2], w2o[4 * r + 3]);
-            ds[i].o2w[r] = make_float4(m[4 * r], m[4 * r + 1], m[4 * r + 2], m[4 * r + 3]);
-            ds[i].w2o[r] = di[i].q[r];
         }
-        ds[i].meta = make_float4(customf, 0.0f, 0.0f, 0.0f);
+        memcpy(&t->host_o2w[12 * (size_t)i], m, 48);
+        t->host_custom[i] = custom;
         di[i].q[3] = make_float4(lo[0], lo[1], lo[2], b->delta);
         di[i].q[4] = make_float4(hi[0], hi[1], hi[2], customf);
         uint64_t pn = (uint64_t)(uintptr_t)b->nodes, pt = (uint64_t)(uintptr_t)b->tris;
@@ -662,7 +661,6 @@ int pt_tlas_build(PtContext* ctx, const PtInstance* instances, uint32_t n, PtTla
     e = hipMalloc((void**)&t->inst, sizeof(PtDevInstance) * n);
     if (e == hipSuccess) e = hipMalloc((void**)&t->shade_inst, sizeof(PtDevShadeInstance) * n);
     if (e == hipSuccess) e = hipMemcpyAsync(t->inst, di.data(), sizeof(PtDevInstance) * n, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(t->shade_inst, ds.data(), sizeof(PtDevShadeInstance) * n, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipEventRecord(ev1, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) { pt_set_error("pt_tlas_build: %s", hipGetErrorString(e)); pt_tlas_destroy(t); return PT_ERROR_HIP; }

@@ -143,6 +143,11 @@ int pt_scene_set_tables(PtContext* c,
     if ((rc = replace_table(&c->geometry_nodes, &c->n_geometry_nodes, geometry_nodes, n_geometry_nodes))) return rc;
     if ((rc = replace_table(&c->blas_instances, &c->n_blas_instances, blas_instances, n_blas_instances))) return rc;
     if ((rc = replace_table(&c->textures, &c->n_textures, textures, n_textures))) return rc;
+    c->h_materials.assign(materials, materials + n_materials);
+    c->h_geometry_nodes.assign(geometry_nodes, geometry_nodes + n_geometry_nodes);
+    c->h_blas_instances.assign(blas_instances, blas_instances + n_blas_instances);
+    c->h_textures.assign(textures, textures + n_textures);
+    c->tables_version++;
     return PT_OK;
 }
 

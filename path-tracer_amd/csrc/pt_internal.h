@@ -33,8 +33,17 @@ void pt_set_error(const char* fmt, ...);
 //   [0..2] world->object rows; [3] = (box lo.xyz, delta); [4] = (box hi.xyz, bits(custom index));
 //   [5] = (nodes pointer lo/hi, triangles pointer lo/hi)
 struct PtDevInstance { float4 q[6]; };
-// Shading view: object->world rows then world->object rows.
-struct PtDevShadeInstance { float4 o2w[3]; float4 w2o[3]; float4 meta; /* x = bits(custom index) */ };
+// Shading view of one instance: the bindless chain blasInstances[custom] -> geometryNodes[first + 0] ->
+// materials[materialIndex] -> textures[albedoMapIndex] (closest_hit.rchit:57-59,75-79) is constant per
+// instance, so it is resolved once on the host into this 160-byte record.
+struct PtDevShadeInstance {
+    float4 o2w[3];
+    float4 w2o[3];
+    float4 ptrs;      // vertex pointer lo/hi, index pointer lo/hi
+    float4 albedo;    // albedoFactor.rgb, bits(useAlbedoMap)
+    float4 emissive;  // emissiveFactor.rgb, -
+    float4 tex;       // texel pointer lo/hi, bits(width), bits(height)
+};
 
 struct PtBlas {
     PtContext* ctx;
@@ -56,7 +65,10 @@ struct PtTlas {
     PtBvhNode* nodes;               // device
     uint32_t* leaf_inst;            // device, instance index per sorted slot
     PtDevInstance* inst;            // device, n
-    PtDevShadeInstance* shade_inst; // device, n
+    PtDevShadeInstance* shade_inst; // device, n; rebuilt when the context's tables change
+    uint64_t shade_version;         // ctx->tables_version the records were built from
+    std::vector<float> host_o2w;    // n x 12
+    std::vector<uint32_t> host_custom;
     std::vector<float> host_boxes;  // n x 6
     std::vector<float> host_w2o;    // n x 12
     float root_lo[3], root_hi[3];
@@ -64,7 +76,8 @@ struct PtTlas {
 };
 
 struct PtWorkspace {
-    uint64_t paths_cap = 0;
+    uint64_t paths_cap = 0;            // slots per stream = kShards * shard_cap
+    uint32_t shard_cap = 0;            // slots per shard (multiple of 64)
     float4* q[2][4] = { { nullptr, nullptr, nullptr, nullptr }, { nullptr, nullptr, nullptr, nullptr } };
     PtHit* hits = nullptr;
     float4* path_result = nullptr;     // per path: final hitValue (xyz)
@@ -88,6 +101,9 @@ struct PtContext {
     PtGeometryNode* geometry_nodes = nullptr; uint32_t n_geometry_nodes = 0;
     PtBLASInstance* blas_instances = nullptr; uint32_t n_blas_instances = 0;
     PtTextureDesc* textures = nullptr; uint32_t n_textures = 0;
+    std::vector<PtMaterial> h_materials; std::vector<PtGeometryNode> h_geometry_nodes;
+    std::vector<PtBLASInstance> h_blas_instances; std::vector<PtTextureDesc> h_textures;
+    uint64_t tables_version = 0;
     PtWorkspace ws;
     uint32_t last_w = 0, last_h = 0;
     // intersect-kernel timing (pt_ctx_set_profiling)

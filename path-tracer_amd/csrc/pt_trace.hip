@@ -10,31 +10,78 @@
 //   q0 = (origin.xyz, bits(seed))   q1 = (direction.xyz, bits(path id))
 //   q2 = (currentWeight.rgb, -)     q3 = (hitValue.rgb, -)
 // so every lane moves 16 bytes per access and a wave moves 1 KiB per instruction.
-// Queue sizes are device-side counters: kernels are launched with a fixed persistent grid and
-// waves pull batches of 64 slots with one atomic each, so a frame needs no host round trip.
+//
+// Ray queues are split into kShards independent shards, each with its own size and work counter
+// on its own 128-byte line.  A single queue head saturates at roughly 90 atomics per microsecond,
+// which for 33 M rays (half a million 64-ray batches) costs more than the traversal itself;
+// 64 heads remove that limit.  Kernels run on a fixed persistent grid: every wave starts at the
+// shard matching its index, pulls 64-slot batches with one atomic each and moves on to the next
+// shard when one runs dry, so sizes stay on the device and a frame needs no host round trip.
+// Survivors of shard s go to shard s of the next queue, which therefore never overflows.
 #include "pt_device.h"
 #include <string.h>
 
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kCounterStride = 64;   // counters: [0,64) queue sizes, [64,128) intersect work, [128,192) shade work
+constexpr int kShards = 64;
+constexpr int kCtrPad = 32;                              // uint32 slots per counter: one 128-byte line each
+constexpr int kCtrPerKind = (PT_MAX_DEPTH + 1) * kShards;
+enum { CTR_COUNT = 0, CTR_WORK_INTERSECT = 1, CTR_WORK_SHADE = 2, CTR_KINDS = 3 };
+constexpr size_t kCounterWords = (size_t)CTR_KINDS * kCtrPerKind * kCtrPad;
 
-__device__ __forceinline__ uint32_t wave_fetch(uint32_t* counter)
+__host__ __device__ inline size_t ctr_index(int kind, uint32_t depth, uint32_t shard)
 {
-    uint32_t base = 0;
-    if ((threadIdx.x & 63) == 0) base = atomicAdd(counter, 64u);
-    return __builtin_amdgcn_readfirstlane(base);
+    return ((size_t)kind * kCtrPerKind + (size_t)depth * kShards + shard) * kCtrPad;
+}
+
+// Batches of 64 paths are dealt round-robin to the shards; the partial last batch is the last
+// batch of its shard, so every shard is dense.
+__device__ __forceinline__ uint32_t slot_of_path(uint32_t q, uint32_t shard_cap)
+{
+    const uint32_t batch = q >> 6;
+    return (batch % kShards) * shard_cap + (batch / kShards) * 64u + (q & 63u);
+}
+__device__ __forceinline__ uint32_t shard_count(uint32_t n, uint32_t s)
+{
+    const uint32_t fb = n >> 6, rem = n & 63u;
+    uint32_t c = (fb / kShards + (s < fb % kShards ? 1u : 0u)) * 64u;
+    if (rem && (fb % kShards) == s) c += rem;
+    return c;
+}
+
+// Calls body(slot index, valid, shard) for every 64-slot batch of one queue level.
+template <typename Body>
+__device__ __forceinline__ void for_each_batch(uint32_t* __restrict__ counters, int work_kind, uint32_t depth,
+                                               uint32_t shard_cap, Body body)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    for (uint32_t k = 0; k < kShards; ++k) {
+        const uint32_t s = (wave + k) & (kShards - 1);
+        const uint32_t n_s = counters[ctr_index(CTR_COUNT, depth, s)];
+        if (n_s == 0) continue;
+        uint32_t* work = &counters[ctr_index(work_kind, depth, s)];
+        for (;;) {
+            // a drained shard costs a load, not an atomic
+            if (__hip_atomic_load(work, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= n_s) break;
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(work, 64u);
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (base >= n_s) break;
+            body(s * shard_cap + base + lane, base + lane < n_s, s);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock)
 k_generate(uint32_t n_paths, uint32_t pixel0, uint32_t spp, uint32_t W, uint32_t H, uint32_t frame, uint32_t seed_mode,
-           const float* __restrict__ cam /* 32 floats, device */, float4* __restrict__ q0, float4* __restrict__ q1,
-           float4* __restrict__ q2, float4* __restrict__ q3, uint32_t* __restrict__ counters)
+           uint32_t shard_cap, const float* __restrict__ cam /* 32 floats, device */, float4* __restrict__ q0,
+           float4* __restrict__ q1, float4* __restrict__ q2, float4* __restrict__ q3, uint32_t* __restrict__ counters)
 {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q == 0) counters[0] = n_paths;
+    if (q < kShards) counters[ctr_index(CTR_COUNT, 0, q)] = shard_count(n_paths, q);
     if (q >= n_paths) return;
     const uint32_t pixel = pixel0 + q / spp, s = q % spp;
     const uint32_t px = pixel % W, py = pixel / W;
@@ -51,15 +98,18 @@ k_generate(uint32_t n_paths, uint32_t pixel0, uint32_t spp, uint32_t W, uint32_t
     float rz = PT_FMA(VI[2], tx, PT_FMA(VI[6], ty, VI[10] * tz));
     uint32_t v1 = seed_mode == PT_SEED_CLOCK ? (uint32_t)clock64() : frame * spp + s;
     uint32_t seed = pt_tea(py * W + px, v1);
-    q0[q] = make_float4(VI[12], VI[13], VI[14], __uint_as_float(seed));
-    q1[q] = make_float4(rx, ry, rz, __uint_as_float(q));
-    q2[q] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
-    q3[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const uint32_t i = slot_of_path(q, shard_cap);
+    q0[i] = make_float4(VI[12], VI[13], VI[14], __uint_as_float(seed));
+    q1[i] = make_float4(rx, ry, rz, __uint_as_float(q));
+    q2[i] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+    q3[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }
 
 // ------------------------------------------------------------------------------------------------
+// BY_ID: hit records go to hits[path id] (pt_intersect: caller's ray order) instead of the queue slot.
+template <bool BY_ID>
 __global__ void __launch_bounds__(kBlock)
-k_intersect(PtTlasView tl, const uint32_t* __restrict__ n_rays_ptr, uint32_t* __restrict__ work,
+k_intersect(PtTlasView tl, uint32_t* __restrict__ counters, uint32_t depth, uint32_t shard_cap,
             const float4* __restrict__ q0, const float4* __restrict__ q1, float tmin, float tmax,
             PtHit* __restrict__ hits, float* __restrict__ t_out, int* __restrict__ spill)
 {
@@ -68,51 +118,44 @@ k_intersect(PtTlasView tl, const uint32_t* __restrict__ n_rays_ptr, uint32_t* __
     stk.lds = &s_stack[0][threadIdx.x];
     stk.lds_stride = kBlock;
     stk.spill = spill + (size_t)(blockIdx.x * blockDim.x + threadIdx.x) * PT_SPILL_STACK;
-    const uint32_t n = *n_rays_ptr;
-    const uint32_t lane = threadIdx.x & 63;
-    for (;;) {
-        const uint32_t base = wave_fetch(work);
-        if (base >= n) break;
-        const uint32_t i = base + lane;
-        if (i < n) {
+    for_each_batch(counters, CTR_WORK_INTERSECT, depth, shard_cap, [&](uint32_t i, bool valid, uint32_t) {
+        if (valid) {
             const float4 o = q0[i], d = q1[i];
             PtHitRec h;
             pt_closest_hit(tl, stk, o.x, o.y, o.z, d.x, d.y, d.z, tmin, tmax, h);
             PtHit out; out.instance = h.inst; out.primitive = h.prim; out.u = h.u; out.v = h.v;
-            hits[i] = out;
-            if (t_out) t_out[i] = h.t;
+            const uint32_t dst = BY_ID ? __float_as_uint(d.w) : i;
+            hits[dst] = out;
+            if (BY_ID && t_out) t_out[dst] = h.t;
         }
-    }
+    });
 }
 
 // rays given as packed float3 arrays (pt_intersect entry point): repack into the float4 streams
-__global__ void k_pack_rays(uint32_t n, const float* __restrict__ o, const float* __restrict__ d,
+__global__ void k_pack_rays(uint32_t n, uint32_t shard_cap, const float* __restrict__ o, const float* __restrict__ d,
                             float4* __restrict__ q0, float4* __restrict__ q1, uint32_t* __restrict__ counters)
 {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) counters[0] = n;
-    if (i >= n) return;
-    q0[i] = make_float4(o[3 * (size_t)i], o[3 * (size_t)i + 1], o[3 * (size_t)i + 2], 0.0f);
-    q1[i] = make_float4(d[3 * (size_t)i], d[3 * (size_t)i + 1], d[3 * (size_t)i + 2], 0.0f);
+    uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < kShards) counters[ctr_index(CTR_COUNT, 0, q)] = shard_count(n, q);
+    if (q >= n) return;
+    const uint32_t i = slot_of_path(q, shard_cap);
+    q0[i] = make_float4(o[3 * (size_t)q], o[3 * (size_t)q + 1], o[3 * (size_t)q + 2], 0.0f);
+    q1[i] = make_float4(d[3 * (size_t)q], d[3 * (size_t)q + 1], d[3 * (size_t)q + 2], __uint_as_float(q));
 }
 
 // ------------------------------------------------------------------------------------------------
-struct PtTables {
-    const PtMaterial* materials;
-    const PtGeometryNode* geometry_nodes;
-    const PtBLASInstance* blas_instances;
-    const PtTextureDesc* textures;
-    const PtDevShadeInstance* shade_inst;
-};
-
 struct __attribute__((aligned(4))) PtVertex { float px, py, pz, nx, ny, nz, tu, tv; };
+
+__device__ __forceinline__ const void* ptr_from(float lo, float hi)
+{
+    return (const void*)(((uint64_t)__float_as_uint(hi) << 32) | __float_as_uint(lo));
+}
 
 // texture(textures[i], uv): LINEAR min/mag, REPEAT, single level, R8G8B8A8_UNORM
 // (include/resources/gpu_resources.hpp:44-63, source/model_loader.cpp:18).
-__device__ __forceinline__ void pt_texture_rgb(const PtTextureDesc& tex, float u, float v, float& r, float& g, float& b)
+__device__ __forceinline__ void pt_texture_rgb(const uint32_t* __restrict__ texels, int W, int H, float u, float v,
+                                               float& r, float& g, float& b)
 {
-    const int W = (int)tex.width, H = (int)tex.height;
-    const uint32_t* texels = (const uint32_t*)(uintptr_t)tex.rgba8_dev;
     float U = PT_FMA(u, (float)W, -0.5f), V = PT_FMA(v, (float)H, -0.5f);
     float fu = floorf(U), fv = floorf(V);
     float a = U - fu, bb = V - fv;
@@ -136,22 +179,18 @@ __device__ __forceinline__ void pt_texture_rgb(const PtTextureDesc& tex, float u
 }
 
 __global__ void __launch_bounds__(kBlock)
-k_shade(PtTables tb, uint32_t depth, uint32_t max_depth, const uint32_t* __restrict__ n_in_ptr, uint32_t* __restrict__ n_out_ptr,
-        uint32_t* __restrict__ work, const PtHit* __restrict__ hits,
+k_shade(const PtDevShadeInstance* __restrict__ shade_inst, uint32_t depth, uint32_t max_depth,
+        uint32_t* __restrict__ counters, uint32_t shard_cap, const PtHit* __restrict__ hits,
         const float4* __restrict__ q0, const float4* __restrict__ q1, const float4* __restrict__ q2, const float4* __restrict__ q3,
         float4* __restrict__ o0, float4* __restrict__ o1, float4* __restrict__ o2, float4* __restrict__ o3,
         float4* __restrict__ path_result)
 {
-    const uint32_t n = *n_in_ptr;
     const uint32_t lane = threadIdx.x & 63;
     const float PI_F = 3.14159265f;
-    for (;;) {
-        const uint32_t base = wave_fetch(work);
-        if (base >= n) break;
-        const uint32_t i = base + lane;
+    for_each_batch(counters, CTR_WORK_SHADE, depth, shard_cap, [&](uint32_t i, bool valid, uint32_t shard) {
         bool alive = false;
         float4 no, nd, nw, nh;
-        if (i < n) {
+        if (valid) {
             const PtHit h = hits[i];
             const uint32_t seed_in = __float_as_uint(q0[i].w);
             const uint32_t path = __float_as_uint(q1[i].w);
@@ -163,16 +202,13 @@ k_shade(PtTables tb, uint32_t depth, uint32_t max_depth, const uint32_t* __restr
                 hv.x = PT_FMA(e, cw.x, hv.x); hv.y = PT_FMA(e, cw.y, hv.y); hv.z = PT_FMA(e, cw.z, hv.z);
                 path_result[path] = hv;
             } else {
-                // closest_hit.rchit:57-60
-                const PtDevShadeInstance& I = tb.shade_inst[h.instance];
-                const uint32_t custom = __float_as_uint(I.meta.x);
-                const PtGeometryNode gn = tb.geometry_nodes[tb.blas_instances[custom].firstGeometryIndex];
-                const PtMaterial* m = &tb.materials[gn.materialIndex];
-                const PtVertex* vertices = (const PtVertex*)(uintptr_t)gn.vertexBufferDeviceAddress;
-                const uint32_t* indices = (const uint32_t*)(uintptr_t)gn.indexBufferDeviceAddress;
-                const PtVertex A = vertices[indices[3 * (size_t)h.primitive + 0]];
-                const PtVertex B = vertices[indices[3 * (size_t)h.primitive + 1]];
-                const PtVertex C = vertices[indices[3 * (size_t)h.primitive + 2]];
+                // closest_hit.rchit:57-60 (table chain pre-resolved per instance)
+                const PtDevShadeInstance& I = shade_inst[h.instance];
+                const float4 ptrs = I.ptrs;
+                const PtVertex* vertices = (const PtVertex*)ptr_from(ptrs.x, ptrs.y);
+                const uint32_t* indices = (const uint32_t*)ptr_from(ptrs.z, ptrs.w);
+                const uint32_t ia = indices[3 * (size_t)h.primitive + 0], ib = indices[3 * (size_t)h.primitive + 1], ic = indices[3 * (size_t)h.primitive + 2];
+                const PtVertex A = vertices[ia], B = vertices[ib], C = vertices[ic];
                 const float b0 = 1.0f - h.u - h.v, b1 = h.u, b2 = h.v;
 #define PT_MIX3(x, y, z) PT_FMA((z), b2, PT_FMA((y), b1, (x) * b0))
                 float px = PT_MIX3(A.px, B.px, C.px), py = PT_MIX3(A.py, B.py, C.py), pz = PT_MIX3(A.pz, B.pz, C.pz);
@@ -216,17 +252,20 @@ k_shade(PtTables tb, uint32_t depth, uint32_t max_depth, const uint32_t* __restr
                 // :71-85
                 float cosTheta = PT_FMA(Dz, Nz, PT_FMA(Dy, Ny, Dx * Nx));
                 float pdf = cosTheta / PI_F;
-                float ar = m->albedoFactor[0], ag = m->albedoFactor[1], ab = m->albedoFactor[2];
-                if (m->useAlbedoMap) {
+                const float4 alb = I.albedo;
+                float ar = alb.x, ag = alb.y, ab = alb.z;
+                if (__float_as_uint(alb.w)) {
+                    const float4 tex = I.tex;
                     float tr, tg, tbb;
-                    pt_texture_rgb(tb.textures[m->albedoMapIndex], tu, tv, tr, tg, tbb);
+                    pt_texture_rgb((const uint32_t*)ptr_from(tex.x, tex.y), (int)__float_as_uint(tex.z), (int)__float_as_uint(tex.w), tu, tv, tr, tg, tbb);
                     ar = ar * tr; ag = ag * tg; ab = ab * tbb;
                 }
                 float wr = (ar / PI_F) * cosTheta / pdf, wg = (ag / PI_F) * cosTheta / pdf, wb = (ab / PI_F) * cosTheta / pdf;
                 // ray_gen.rgen:67-68
-                hv.x = PT_FMA(m->emissiveFactor[0], cw.x, hv.x);
-                hv.y = PT_FMA(m->emissiveFactor[1], cw.y, hv.y);
-                hv.z = PT_FMA(m->emissiveFactor[2], cw.z, hv.z);
+                const float4 em = I.emissive;
+                hv.x = PT_FMA(em.x, cw.x, hv.x);
+                hv.y = PT_FMA(em.y, cw.y, hv.y);
+                hv.z = PT_FMA(em.z, cw.z, hv.z);
                 if (depth + 1 < max_depth) {
                     alive = true;
                     no = make_float4(wx, wy, wz, __uint_as_float(seed));
@@ -238,19 +277,19 @@ k_shade(PtTables tb, uint32_t depth, uint32_t max_depth, const uint32_t* __restr
                 }
             }
         }
-        // wave-level compaction: one atomic per wave, lanes take consecutive slots
+        // wave-level compaction into the same shard of the next queue: one atomic per batch
         const unsigned long long bal = __ballot(alive);
         const uint32_t cnt = __popcll(bal);
         if (cnt) {
             uint32_t slot0 = 0;
-            if (lane == 0) slot0 = atomicAdd(n_out_ptr, cnt);
+            if (lane == 0) slot0 = atomicAdd(&counters[ctr_index(CTR_COUNT, depth + 1, shard)], cnt);
             slot0 = __builtin_amdgcn_readfirstlane(slot0);
             if (alive) {
-                const uint32_t slot = slot0 + __popcll(bal & ((1ull << lane) - 1ull));
+                const uint32_t slot = shard * shard_cap + slot0 + __popcll(bal & ((1ull << lane) - 1ull));
                 o0[slot] = no; o1[slot] = nd; o2[slot] = nw; o3[slot] = nh;
             }
         }
-    }
+    });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -301,9 +340,11 @@ k_accumulate(uint32_t n_pixels, uint32_t pixel0, uint32_t spp, uint32_t frame, u
 
 __global__ void k_stats(const uint32_t* __restrict__ counters, uint32_t max_depth, uint32_t n_paths, uint64_t* __restrict__ stats)
 {
-    uint32_t d = threadIdx.x;
-    if (d < max_depth) stats[d] += counters[d];
-    if (d == 0) stats[PT_MAX_DEPTH] += n_paths;
+    const uint32_t d = blockIdx.x, s = threadIdx.x;   // one wave per depth, one lane per shard
+    uint32_t c = (d < max_depth && s < kShards) ? counters[ctr_index(CTR_COUNT, d, s)] : 0u;
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+    if (s == 0 && d < max_depth) stats[d] += c;
+    if (s == 0 && d == 0) stats[PT_MAX_DEPTH] += n_paths;
 }
 
 __global__ void k_resolve(uint32_t n, const float4* __restrict__ sum, uchar4* __restrict__ out, int bgra)
@@ -329,35 +370,73 @@ int persistent_blocks(PtContext* ctx, const void* kernel)
     return ctx->num_cus * per_cu;
 }
 
-struct Workspace {
-    static int ensure(PtContext* ctx, uint64_t paths, uint64_t pixels)
-    {
-        PtWorkspace& w = ctx->ws;
-        if (!w.counters) {
-            PT_HIP_CHECK(hipMalloc((void**)&w.counters, sizeof(uint32_t) * 3 * kCounterStride));
-            PT_HIP_CHECK(hipMalloc((void**)&w.stats, sizeof(uint64_t) * (PT_MAX_DEPTH + 1)));
-            PT_HIP_CHECK(hipMemset(w.stats, 0, sizeof(uint64_t) * (PT_MAX_DEPTH + 1)));
-            PT_HIP_CHECK(hipMalloc((void**)&w.cam, sizeof(float) * 32));
-            w.spill_threads = (uint64_t)ctx->num_cus * 8 * kBlock;
-            PT_HIP_CHECK(hipMalloc((void**)&w.spill, sizeof(int) * PT_SPILL_STACK * w.spill_threads));
-        }
-        if (paths > w.paths_cap) {
-            for (int a = 0; a < 2; ++a) for (int k = 0; k < 4; ++k) { (void)hipFree(w.q[a][k]); w.q[a][k] = nullptr; }
-            (void)hipFree(w.hits); (void)hipFree(w.path_result); w.hits = nullptr; w.path_result = nullptr;
-            w.paths_cap = 0;
-            for (int a = 0; a < 2; ++a) for (int k = 0; k < 4; ++k) PT_HIP_CHECK(hipMalloc((void**)&w.q[a][k], sizeof(float4) * paths));
-            PT_HIP_CHECK(hipMalloc((void**)&w.hits, sizeof(PtHit) * paths));
-            PT_HIP_CHECK(hipMalloc((void**)&w.path_result, sizeof(float4) * paths));
-            w.paths_cap = paths;
-        }
-        if (pixels > w.frame_pixels_cap) {
-            (void)hipFree(w.frame_result); w.frame_result = nullptr; w.frame_pixels_cap = 0;
-            PT_HIP_CHECK(hipMalloc((void**)&w.frame_result, sizeof(float) * 3 * pixels));
-            w.frame_pixels_cap = pixels;
-        }
-        return PT_OK;
+int ensure_workspace(PtContext* ctx, uint64_t paths, uint64_t pixels)
+{
+    PtWorkspace& w = ctx->ws;
+    if (!w.counters) {
+        PT_HIP_CHECK(hipMalloc((void**)&w.counters, sizeof(uint32_t) * kCounterWords));
+        PT_HIP_CHECK(hipMalloc((void**)&w.stats, sizeof(uint64_t) * (PT_MAX_DEPTH + 1)));
+        PT_HIP_CHECK(hipMemset(w.stats, 0, sizeof(uint64_t) * (PT_MAX_DEPTH + 1)));
+        PT_HIP_CHECK(hipMalloc((void**)&w.cam, sizeof(float) * 32));
+        w.spill_threads = (uint64_t)ctx->num_cus * 8 * kBlock;
+        PT_HIP_CHECK(hipMalloc((void**)&w.spill, sizeof(int) * PT_SPILL_STACK * w.spill_threads));
     }
-};
+    // per-shard capacity: the batches dealt to one shard, in slots
+    const uint64_t batches = (paths + 63) / 64;
+    const uint64_t cap = ((batches + kShards - 1) / kShards) * 64;
+    if (cap > w.shard_cap) {
+        for (int a = 0; a < 2; ++a) for (int k = 0; k < 4; ++k) { (void)hipFree(w.q[a][k]); w.q[a][k] = nullptr; }
+        (void)hipFree(w.hits); (void)hipFree(w.path_result); w.hits = nullptr; w.path_result = nullptr;
+        w.paths_cap = 0; w.shard_cap = 0;
+        const uint64_t slots = cap * kShards;
+        for (int a = 0; a < 2; ++a) for (int k = 0; k < 4; ++k) PT_HIP_CHECK(hipMalloc((void**)&w.q[a][k], sizeof(float4) * slots));
+        PT_HIP_CHECK(hipMalloc((void**)&w.hits, sizeof(PtHit) * slots));
+        PT_HIP_CHECK(hipMalloc((void**)&w.path_result, sizeof(float4) * slots));
+        w.paths_cap = slots; w.shard_cap = (uint32_t)cap;
+    }
+    if (pixels > w.frame_pixels_cap) {
+        (void)hipFree(w.frame_result); w.frame_result = nullptr; w.frame_pixels_cap = 0;
+        PT_HIP_CHECK(hipMalloc((void**)&w.frame_result, sizeof(float) * 3 * pixels));
+        w.frame_pixels_cap = pixels;
+    }
+    return PT_OK;
+}
+
+// Resolves blasInstances[custom] -> geometryNodes -> materials -> textures once per instance.
+int ensure_shade_records(PtContext* ctx, const PtTlas* tlas_c)
+{
+    PtTlas* t = const_cast<PtTlas*>(tlas_c);
+    if (t->shade_version == ctx->tables_version && ctx->tables_version != 0) return PT_OK;
+    std::vector<PtDevShadeInstance> rec(t->n);
+    auto split = [](uint64_t p, float& lo, float& hi) { uint32_t a = (uint32_t)p, b = (uint32_t)(p >> 32); memcpy(&lo, &a, 4); memcpy(&hi, &b, 4); };
+    auto bits = [](uint32_t v) { float f; memcpy(&f, &v, 4); return f; };
+    for (uint32_t i = 0; i < t->n; ++i) {
+        const uint32_t custom = t->host_custom[i];
+        if (custom >= ctx->h_blas_instances.size()) { pt_set_error("pt_trace: instance %u has custom index %u but only %zu BLASInstance records exist", i, custom, ctx->h_blas_instances.size()); return PT_ERROR_INVALID_ARGUMENT; }
+        const PtGeometryNode& gn = ctx->h_geometry_nodes[ctx->h_blas_instances[custom].firstGeometryIndex];
+        const PtMaterial& m = ctx->h_materials[gn.materialIndex];
+        PtDevShadeInstance& r = rec[i];
+        const float* o = &t->host_o2w[12 * (size_t)i]; const float* w = &t->host_w2o[12 * (size_t)i];
+        for (int k = 0; k < 3; ++k) {
+            r.o2w[k] = make_float4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
+            r.w2o[k] = make_float4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
+        }
+        split(gn.vertexBufferDeviceAddress, r.ptrs.x, r.ptrs.y);
+        split(gn.indexBufferDeviceAddress, r.ptrs.z, r.ptrs.w);
+        r.albedo = make_float4(m.albedoFactor[0], m.albedoFactor[1], m.albedoFactor[2], bits(m.useAlbedoMap ? 1u : 0u));
+        r.emissive = make_float4(m.emissiveFactor[0], m.emissiveFactor[1], m.emissiveFactor[2], 0.0f);
+        r.tex = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (m.useAlbedoMap) {
+            const PtTextureDesc& td = ctx->h_textures[m.albedoMapIndex];
+            split(td.rgba8_dev, r.tex.x, r.tex.y);
+            r.tex.z = bits(td.width); r.tex.w = bits(td.height);
+        }
+    }
+    PT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    PT_HIP_CHECK(hipMemcpy(t->shade_inst, rec.data(), sizeof(PtDevShadeInstance) * t->n, hipMemcpyHostToDevice));
+    t->shade_version = ctx->tables_version;
+    return PT_OK;
+}
 
 PtTlasView view_of(const PtTlas* t)
 {
@@ -377,15 +456,15 @@ int pt_intersect(PtContext* ctx, const PtTlas* tlas, uint32_t n, const float* or
     PT_REQUIRE(tlas->ctx == ctx, "the TLAS belongs to another context");
     if (n == 0) return PT_OK;
     PT_HIP_CHECK(hipSetDevice(ctx->device));
-    int rc = Workspace::ensure(ctx, n, 0);
+    int rc = ensure_workspace(ctx, n, 0);
     if (rc) return rc;
     PtWorkspace& w = ctx->ws;
     hipStream_t st = ctx->stream;
-    PT_HIP_CHECK(hipMemsetAsync(w.counters, 0, sizeof(uint32_t) * 3 * kCounterStride, st));
-    k_pack_rays<<<(n + kBlock - 1) / kBlock, kBlock, 0, st>>>(n, origins_dev, dirs_dev, w.q[0][0], w.q[0][1], w.counters);
-    int blocks = persistent_blocks(ctx, (const void*)k_intersect);
-    k_intersect<<<blocks, kBlock, 0, st>>>(view_of(tlas), w.counters, w.counters + kCounterStride, w.q[0][0], w.q[0][1],
-                                           tmin, tmax, hits_dev, t_dev, w.spill);
+    PT_HIP_CHECK(hipMemsetAsync(w.counters, 0, sizeof(uint32_t) * kCounterWords, st));
+    k_pack_rays<<<(n + kBlock - 1) / kBlock, kBlock, 0, st>>>(n, w.shard_cap, origins_dev, dirs_dev, w.q[0][0], w.q[0][1], w.counters);
+    int blocks = persistent_blocks(ctx, (const void*)k_intersect<true>);
+    k_intersect<true><<<blocks, kBlock, 0, st>>>(view_of(tlas), w.counters, 0, w.shard_cap, w.q[0][0], w.q[0][1],
+                                                 tmin, tmax, hits_dev, t_dev, w.spill);
     PT_HIP_CHECK(hipGetLastError());
     return PT_OK;
 }
@@ -399,31 +478,29 @@ int pt_trace(PtContext* ctx, const PtTlas* tlas, const float camera[32], uint32_
     PT_REQUIRE(spp > 0 && spp <= 65536, "samples_per_frame must be in [1, 65536]");
     PT_REQUIRE(max_depth > 0 && max_depth < PT_MAX_DEPTH, "max_depth must be in [1, 63]");
     PT_REQUIRE(seed_mode <= PT_SEED_CLOCK && accum_mode <= PT_ACCUM_MEAN_UNORM8, "bad mode");
-    PT_REQUIRE(ctx->materials && ctx->geometry_nodes && ctx->blas_instances, "pt_scene_set_tables has not been called");
-    PT_REQUIRE(ctx->n_blas_instances >= tlas->n, "fewer BLASInstance records than TLAS instances");
+    PT_REQUIRE(ctx->tables_version != 0, "pt_scene_set_tables has not been called");
     PT_HIP_CHECK(hipSetDevice(ctx->device));
+    int rc = ensure_shade_records(ctx, tlas);
+    if (rc) return rc;
     const uint64_t n_pixels = (uint64_t)width * height;
     uint64_t chunk_pixels = ctx->max_paths / spp;
     if (chunk_pixels < 1) chunk_pixels = 1;
     if (chunk_pixels > n_pixels) chunk_pixels = n_pixels;
-    PT_REQUIRE(chunk_pixels * spp < (1ull << 32), "max_paths too large");
-    int rc = Workspace::ensure(ctx, chunk_pixels * spp, n_pixels);
+    PT_REQUIRE(chunk_pixels * spp < (1ull << 31), "max_paths too large");
+    rc = ensure_workspace(ctx, chunk_pixels * spp, n_pixels);
     if (rc) return rc;
     PtWorkspace& w = ctx->ws;
     hipStream_t st = ctx->stream;
     PT_HIP_CHECK(hipMemcpyAsync(w.cam, camera, sizeof(float) * 32, hipMemcpyHostToDevice, st));
-    PtTables tb;
-    tb.materials = ctx->materials; tb.geometry_nodes = ctx->geometry_nodes; tb.blas_instances = ctx->blas_instances;
-    tb.textures = ctx->textures; tb.shade_inst = tlas->shade_inst;
     const PtTlasView tv = view_of(tlas);
-    const int blocks_i = persistent_blocks(ctx, (const void*)k_intersect);
+    const int blocks_i = persistent_blocks(ctx, (const void*)k_intersect<false>);
     const int blocks_s = persistent_blocks(ctx, (const void*)k_shade);
     for (uint64_t p0 = 0; p0 < n_pixels; p0 += chunk_pixels) {
         const uint32_t np = (uint32_t)((n_pixels - p0) < chunk_pixels ? (n_pixels - p0) : chunk_pixels);
         const uint32_t n_paths = np * spp;
-        PT_HIP_CHECK(hipMemsetAsync(w.counters, 0, sizeof(uint32_t) * 3 * kCounterStride, st));
-        k_generate<<<(n_paths + kBlock - 1) / kBlock, kBlock, 0, st>>>(n_paths, (uint32_t)p0, spp, width, height, frame, seed_mode, w.cam,
-                                                                      w.q[0][0], w.q[0][1], w.q[0][2], w.q[0][3], w.counters);
+        PT_HIP_CHECK(hipMemsetAsync(w.counters, 0, sizeof(uint32_t) * kCounterWords, st));
+        k_generate<<<(n_paths + kBlock - 1) / kBlock, kBlock, 0, st>>>(n_paths, (uint32_t)p0, spp, width, height, frame, seed_mode, w.shard_cap,
+                                                                      w.cam, w.q[0][0], w.q[0][1], w.q[0][2], w.q[0][3], w.counters);
         for (uint32_t d = 0; d < max_depth; ++d) {
             const int a = d & 1, b = a ^ 1;
             hipEvent_t ev_stop = nullptr;
@@ -437,15 +514,15 @@ int pt_trace(PtContext* ctx, const PtTlas* tlas, const float camera[32], uint32_
                 ev_stop = ctx->ev_pool[ctx->ev_used + 1];
                 ctx->ev_used += 2;
             }
-            k_intersect<<<blocks_i, kBlock, 0, st>>>(tv, w.counters + d, w.counters + kCounterStride + d, w.q[a][0], w.q[a][1],
-                                                     0.001f, 10000.0f, w.hits, nullptr, w.spill);
+            k_intersect<false><<<blocks_i, kBlock, 0, st>>>(tv, w.counters, d, w.shard_cap, w.q[a][0], w.q[a][1],
+                                                            0.001f, 10000.0f, w.hits, nullptr, w.spill);
             if (ev_stop) PT_HIP_CHECK(hipEventRecord(ev_stop, st));
-            k_shade<<<blocks_s, kBlock, 0, st>>>(tb, d, max_depth, w.counters + d, w.counters + d + 1, w.counters + 2 * kCounterStride + d, w.hits,
+            k_shade<<<blocks_s, kBlock, 0, st>>>(tlas->shade_inst, d, max_depth, w.counters, w.shard_cap, w.hits,
                                                  w.q[a][0], w.q[a][1], w.q[a][2], w.q[a][3], w.q[b][0], w.q[b][1], w.q[b][2], w.q[b][3],
                                                  w.path_result);
         }
         k_accumulate<<<(np + kBlock - 1) / kBlock, kBlock, 0, st>>>(np, (uint32_t)p0, spp, frame, accum_mode, w.path_result, w.frame_result, accum_dev);
-        k_stats<<<1, 64, 0, st>>>(w.counters, max_depth, n_paths, w.stats);
+        k_stats<<<max_depth, 64, 0, st>>>(w.counters, max_depth, n_paths, w.stats);
     }
     PT_HIP_CHECK(hipGetLastError());
     ctx->last_w = width; ctx->last_h = height;
