@@ -54,11 +54,11 @@ def cpu_baseline(scene, width, height, spp, max_depth):
     }
 
 
-def run_steps(renderer, accum_ptr, n_steps, first_frame, frame_stride, spp, max_depth):
-    from pt_amd import hip
-    for k in range(n_steps):
-        renderer.render(spp=spp, max_depth=max_depth, accum_mode=hip.ACCUM_SUM_F32, accum_dev=accum_ptr,
-                        frame=first_frame + k * frame_stride)
+def run_steps(renderer, accum_ptr, n_steps, first_frame, rank, world, spp, max_depth):
+    """Rank `rank` renders its share of the frames [first_frame, first_frame + n_steps * world)."""
+    from pt_amd import hip, sharding
+    for f in sharding.frames_for_rank(rank, world, n_steps * world, first_frame):
+        renderer.render(spp=spp, max_depth=max_depth, accum_mode=hip.ACCUM_SUM_F32, accum_dev=accum_ptr, frame=f)
 
 
 def main():
@@ -78,7 +78,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from pt_amd import hip
+    from pt_amd import hip, sharding
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -106,14 +106,13 @@ def main():
         torch.cuda.synchronize()
 
     # warmup (frames that are not part of the timed set)
-    run_steps(r, accum.data_ptr(), args.warmup, 1_000_000 + rank, world, args.spp, args.max_depth)
+    run_steps(r, accum.data_ptr(), args.warmup, 1_000_000, rank, world, args.spp, args.max_depth)
     accum.zero_()
     r.reset_stats()
     barrier()
     t0 = time.perf_counter()
-    run_steps(r, accum.data_ptr(), args.steps, rank, world, args.spp, args.max_depth)
-    if world > 1:
-        dist.all_reduce(accum, op=dist.ReduceOp.SUM)
+    run_steps(r, accum.data_ptr(), args.steps, 0, rank, world, args.spp, args.max_depth)
+    sharding.allreduce_sum(accum)
     barrier()
     elapsed = time.perf_counter() - t0
     st = r.stats()
@@ -133,7 +132,7 @@ def main():
     # --- dominant kernel (intersect) timed with HIP events on the stream it runs on
     r.set_profiling(True)
     r.profile()
-    run_steps(r, accum.data_ptr(), min(args.steps, 4), 2_000_000 + rank, world, args.spp, args.max_depth)
+    run_steps(r, accum.data_ptr(), min(args.steps, 4), 2_000_000, rank, world, args.spp, args.max_depth)
     prof = r.profile()
     r.set_profiling(False)
 
@@ -179,11 +178,11 @@ def main():
             r.close()
             c = hip.Renderer(build_scene("cornell"), W, H, device=local_rank, stream=stream)
             acc2 = torch.zeros(H * W * 4, dtype=torch.float32, device="cuda")
-            run_steps(c, acc2.data_ptr(), 1, 1_000_000, 1, args.spp, args.max_depth)
+            run_steps(c, acc2.data_ptr(), 1, 1_000_000, 0, 1, args.spp, args.max_depth)
             c.reset_stats()
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            run_steps(c, acc2.data_ptr(), 3, 0, 1, args.spp, args.max_depth)
+            run_steps(c, acc2.data_ptr(), 3, 0, 0, 1, args.spp, args.max_depth)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t1
             s2 = c.stats()

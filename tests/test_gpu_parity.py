@@ -104,6 +104,40 @@ def test_render_frame_bit_exact(name, w, h, spp, request):
         r.close()
 
 
+def test_cfg1_golden_full_size(cornell):
+    """BASELINE config 1 in full (Cornell 512x512, 16 spp, frame 0) against the committed oracle
+    outputs: SHA-256 of the whole float image, the radiance crop, the ray count and the bounce-0 ids."""
+    import hashlib
+    import os
+    from conftest import GOLDEN
+    from pt_amd import camera
+    import oracle as O
+    g = np.load(os.path.join(GOLDEN, "cfg1_cornell_512_16spp.npz"))
+    W = H = 512
+    r = _renderer(cornell, W, H)
+    try:
+        r.render(spp=16, max_depth=10, frame=0)
+        got = r.last_result()
+        assert int(r.stats()["rays"]) == int(g["rays"])
+        assert np.array_equal(got[192:320, 192:320], g["crop"])
+        assert hashlib.sha256(got.tobytes()).digest() == g["sha256"].tobytes()
+        cam = camera.camera_uniform(W, H)
+        o = np.zeros((H * W, 3), np.float32)
+        d = np.zeros((H * W, 3), np.float32)
+        for y in range(0, H, 4):               # every fourth row keeps the host loop short
+            for x in range(W):
+                o[y * W + x], d[y * W + x] = O.primary_ray(cam, W, H, x, y)
+        rows = np.arange(0, H, 4)
+        sel = (rows[:, None] * W + np.arange(W)[None, :]).reshape(-1)
+        hits, _ = r.intersect(o[sel], d[sel])
+        ids = g["bounce0_ids"].reshape(-1, 2)[sel]
+        inst = np.where(hits["instance"] == 0xFFFFFFFF, 255, hits["instance"]).astype(np.uint8)
+        prim = np.where(hits["primitive"] == 0xFFFFFFFF, 255, hits["primitive"]).astype(np.uint8)
+        assert np.array_equal(inst, ids[:, 0]) and np.array_equal(prim, ids[:, 1])
+    finally:
+        r.close()
+
+
 def test_ray_counts_match_oracle(cornell):
     from pt_amd import camera
     orc = _oracle(cornell)

@@ -1,0 +1,108 @@
+"""Host logic: scene import conventions, fixtures, camera, sharding schedule."""
+import os
+
+import numpy as np
+import pytest
+
+from pt_amd import abi, camera, gltf, sharding
+from pt_amd.scene import Scene, mat4_mul
+
+REF_ASSETS = "/root/reference/assets"
+needs_ref = pytest.mark.skipif(not os.path.isdir(REF_ASSETS), reason="reference checkout not mounted")
+
+
+def test_scene_npz_roundtrip(tmp_path, cube):
+    p = str(tmp_path / "s.npz")
+    cube.save_npz(p)
+    s = Scene.load_npz(p)
+    assert np.array_equal(s.models[0].vertices, cube.models[0].vertices)
+    assert np.array_equal(s.models[0].indices, cube.models[0].indices)
+    assert np.array_equal(s.tables.material_array(), cube.tables.material_array())
+    assert all(np.array_equal(a, b) for a, b in zip(s.tables.images, cube.tables.images))
+    assert [(i.model, i.node, i.mesh) for i in s.instances()] == [(i.model, i.node, i.mesh) for i in cube.instances()]
+
+
+def test_cube_fixture_tables(cube):
+    """Image 0 is the 2x2 zero fallback (bindless_resources.cpp:52-61); the cube's base colour is
+    image 1 and its metallic-roughness map image 2 (load order of ProcessMaterial)."""
+    imgs = cube.tables.images
+    assert imgs[0].shape == (2, 2, 4) and not imgs[0].any()
+    assert imgs[1].shape == (512, 512, 4)
+    m = cube.tables.material_array()[0]
+    assert m["useAlbedoMap"] == 1 and m["albedoMapIndex"] == 1 and m["useMRMap"] == 1 and m["mrMapIndex"] == 2
+    assert m["useNormalMap"] == 0 and m["normalMapIndex"] == abi.NULL_RESOURCE_INDEX_VALUE
+    uv = cube.models[0].vertices["uv"]
+    assert uv.min() < 0.0 and uv.max() <= 1.0 + 1e-6      # exercises REPEAT addressing
+
+
+@needs_ref
+@pytest.mark.parametrize("name,rel", [("cornell", "cornell/CornellBox-Original.gltf"), ("cube", "cube/Cube.gltf")])
+def test_fixture_matches_fresh_import(name, rel, request):
+    fresh = Scene()
+    gltf.load_from_file(fresh, os.path.join(REF_ASSETS, rel))
+    fx = request.getfixturevalue(name)
+    assert np.array_equal(fresh.models[0].vertices, fx.models[0].vertices)
+    assert np.array_equal(fresh.models[0].indices, fx.models[0].indices)
+    assert np.array_equal(fresh.tables.material_array(), fx.tables.material_array())
+
+
+@needs_ref
+def test_helmet_import_conventions():
+    s = Scene()
+    m = gltf.load_from_file(s, os.path.join(REF_ASSETS, "helmet/FlightHelmet.gltf"))
+    inst = s.instances()
+    assert len(inst) == 5 and len(m.nodes) == 6 and m.nodes[0].name == "FlightHelmet"
+    assert [m.meshes[i.mesh].index_count // 3 for i in inst] == [8136, 21896, 736, 20096, 43858]
+    assert len(m.vertices) == 60366
+    # root rotation of 180 degrees about Y is applied to every child
+    assert np.allclose(inst[0].world[:3, :3], np.diag([-1, 1, -1]), atol=1e-6)
+    assert np.allclose(inst[1].world[:3, 3], (-0.000434499962, 0.032592997, -0.011676996), atol=1e-7)
+    mats = s.tables.material_array()
+    # FlightHelmet_baseColor1.png is absent from the checkout: factor-only material, null handle
+    assert mats[1]["useAlbedoMap"] == 0 and mats[1]["albedoMapIndex"] == abi.NULL_RESOURCE_INDEX_VALUE
+    assert mats[0]["useAlbedoMap"] == 1 and mats[0]["albedoMapIndex"] == 1
+
+
+@needs_ref
+def test_dragon_gltf_nodes_match_the_standin(dragon):
+    """The stand-in uses the node transforms and mesh sizes DragonAttenuation.gltf states."""
+    import json
+    j = json.load(open(os.path.join(REF_ASSETS, "dragon/DragonAttenuation.gltf")))
+    assert j["accessors"][3]["count"] == 43779 * 3 and j["accessors"][7]["count"] == 91216 * 3
+    inst = dragon.instances()
+    assert np.allclose(inst[0].world[:3, :3], np.eye(3) * 3.5)
+    assert np.allclose(inst[0].world[:3, 3], j["nodes"][0]["translation"])
+    assert np.allclose(np.abs(inst[1].world[:3, :3]).sum(), 0.75, atol=1e-5)
+
+
+def test_world_matrix_is_product_up_the_parent_chain():
+    from pt_amd.scene import Model, Node
+    a = np.eye(4, dtype=np.float32); a[0, 3] = 2
+    b = np.eye(4, dtype=np.float32); b[1, 1] = 3
+    m = Model(vertices=np.zeros(0, abi.VERTEX), indices=np.zeros(0, np.uint32))
+    m.nodes = [Node("root", None, a), Node("child", 0, b)]
+    assert np.array_equal(m.world_matrix(1), mat4_mul(a, b))
+
+
+def test_camera_uniform_layout():
+    cam = camera.camera_uniform(1920, 1080)
+    vi = cam[:16].reshape(4, 4).T
+    pi = cam[16:].reshape(4, 4).T
+    assert np.allclose(vi, [[1, 0, 0, 0], [0, 1, 0, 1], [0, 0, 1, 3], [0, 0, 0, 1]])
+    t = np.tan(np.radians(30.0))
+    assert np.allclose(pi[0, 0], 1920 / 1080 * t, rtol=1e-6) and np.allclose(pi[1, 1], -t, rtol=1e-6)
+    assert np.allclose(pi[2, 3], -1.0) and np.allclose(pi[3, 2], -1 / 0.10001, rtol=1e-4)
+
+
+def test_instance_record_layout():
+    w = np.arange(12, dtype=np.float32).reshape(3, 4)
+    r = abi.make_instance(w, 5, 0x1234)
+    assert r["customIndexAndMask"] == (0xFF << 24 | 5) and r["sbtOffsetAndFlags"] == (1 << 24)
+    assert np.array_equal(r["transform"], w.reshape(12)) and r["blasRef"] == 0x1234
+
+
+def test_frame_schedule_partitions_the_frames():
+    for world in (1, 2, 4, 8):
+        for n in (1, 7, 16):
+            got = sorted(f for r in range(world) for f in sharding.frames_for_rank(r, world, n, first_frame=3))
+            assert got == list(range(3, 3 + n))
