@@ -139,6 +139,39 @@ class Scene:
             d[f"m{mi}_textures"] = np.array(m.textures, dtype=np.uint32)
         np.savez_compressed(path, **d)
 
+    def save_ptscene(self, path):
+        """Little-endian container read by the C++ ModelLoader (host/model_loader.cpp: LoadPtScene):
+        "PTSC1", images (index 0 = fallback), materials, one model."""
+        import struct
+        assert len(self.models) == 1, "a .ptscene holds exactly one model"
+        m = self.models[0]
+        with open(path, "wb") as f:
+            f.write(b"PTSC1\0\0\0")
+            f.write(struct.pack("<I", len(self.tables.images)))
+            for img in self.tables.images:
+                f.write(struct.pack("<II", img.shape[1], img.shape[0]))
+                f.write(np.ascontiguousarray(img).tobytes())
+            mats = self.tables.material_array()
+            f.write(struct.pack("<I", len(mats)))
+            f.write(mats.tobytes())
+            f.write(struct.pack("<I", 1))
+            f.write(struct.pack("<I", len(m.vertices)))
+            f.write(m.vertices.tobytes())
+            f.write(struct.pack("<I", len(m.indices)))
+            f.write(m.indices.astype("<u4").tobytes())
+            f.write(struct.pack("<I", len(m.meshes)))
+            for x in m.meshes:
+                f.write(struct.pack("<IIII", x.index_count, x.first_index, x.first_vertex, x.material))
+            f.write(struct.pack("<I", len(m.nodes)))
+            for n in m.nodes:
+                f.write(struct.pack("<i", -1 if n.parent is None else n.parent))
+                f.write(np.ascontiguousarray(n.local_matrix, dtype="<f4").tobytes())
+                f.write(struct.pack("<I", len(n.meshes)))
+                f.write(np.array(n.meshes, dtype="<u4").tobytes())
+                name = n.name.encode()
+                f.write(struct.pack("<I", len(name)))
+                f.write(name)
+
     @staticmethod
     def load_npz(path):
         z = np.load(path, allow_pickle=False)
