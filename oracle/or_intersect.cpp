@@ -36,11 +36,12 @@ void or_ray_space_init(RaySpace& rs, V3 o, V3 d)
     int kx = (kz + 1) % 3, ky = (kx + 1) % 3;
     if (comp(d, kz) < 0.0f) { int t = kx; kx = ky; ky = t; }
     rs.kx = kx; rs.ky = ky; rs.kz = kz;
+    /* a usable dominant component is required; the shear uses the reciprocal, not two more divisions */
     float dz = comp(d, kz);
-    rs.valid = dz != 0.0f;
-    rs.Sx = comp(d, kx) / dz;
-    rs.Sy = comp(d, ky) / dz;
+    rs.valid = fabsf(dz) > eps;
     rs.Sz = 1.0f / dz;
+    rs.Sx = comp(d, kx) * rs.Sz;
+    rs.Sy = comp(d, ky) * rs.Sz;
 }
 
 void or_slab(const RaySpace& rs, const Box& b, float& tn, float& tf)
@@ -204,5 +205,17 @@ extern "C" void or_intersect(const OrTlas* tlas, uint32_t n, const float* origin
         hits[r].primitive = h.hit ? h.prim : 0xFFFFFFFFu;
         hits[r].u = h.u; hits[r].v = h.v;
         if (t_out) t_out[r] = h.hit ? h.t : tmax;
+    }
+}
+
+/* per-ray traversal work (box tests, triangle tests) for analysing wave-level divergence */
+extern "C" void or_intersect_counts(const OrTlas* tlas, uint32_t n, const float* origins, const float* dirs,
+                                    float tmin, float tmax, uint32_t* box_tests, uint32_t* tri_tests)
+{
+    for (uint32_t r = 0; r < n; ++r) {
+        HitRec h; OrStats st; memset(&st, 0, sizeof st);
+        or_closest_hit(tlas, V3 { origins[3 * r], origins[3 * r + 1], origins[3 * r + 2] },
+                       V3 { dirs[3 * r], dirs[3 * r + 1], dirs[3 * r + 2] }, tmin, tmax, true, h, &st);
+        box_tests[r] = (uint32_t)st.box_tests; tri_tests[r] = (uint32_t)st.tri_tests;
     }
 }

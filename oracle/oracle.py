@@ -52,6 +52,7 @@ def _load():
         "or_scene_create": (vp, [vp, vp, u32, vp, u32, vp, u32, vp, u32]),
         "or_scene_destroy": (None, [vp]),
         "or_intersect": (None, [vp, u32, vp, vp, f, f, i, vp, vp, vp]),
+        "or_intersect_counts": (None, [vp, u32, vp, vp, f, f, vp, vp]),
         "or_render_frame": (None, [vp, vp, u32, u32, u32, u32, u32, u32, u32, u32, u32, i, i, vp, vp]),
         "or_trace_path": (u32, [vp, vp, u32, u32, u32, u32, u32, u32, vp, vp]),
         "or_accumulate": (None, [i, u32, u32, vp, vp]),

@@ -140,6 +140,9 @@ void     or_scene_destroy(OrScene*);
 void or_intersect(const OrTlas* tlas, uint32_t n, const float* origins, const float* dirs,
                   float tmin, float tmax, int mode, OrHit* hits, float* t_out, OrStats* stats);
 
+void or_intersect_counts(const OrTlas* tlas, uint32_t n, const float* origins, const float* dirs,
+                         float tmin, float tmax, uint32_t* box_tests, uint32_t* tri_tests);
+
 /* ---- one frame of ray_gen.rgen over the pixel rectangle [x0,x1) x [y0,y1).
  * result: float3 per pixel of the FULL image (row-major, W*H*3), only the rectangle is written.
  * seed for sample i of this frame: TEA(y*W+x, frame*spp + i). */

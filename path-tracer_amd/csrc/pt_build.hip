@@ -360,6 +360,24 @@ __global__ void k_pack_tris(const uint8_t* __restrict__ vertices, uint32_t strid
     tris[3 * (size_t)i + 2] = make_float4(c[2], __uint_as_float(p), 0.0f, 0.0f);
 }
 
+// Copies a BLAS into the TLAS-owned pool: inner references move by node_base, leaf references by
+// tri_base, so that traversal follows absolute indices and needs no per-instance base pointers.
+__global__ void k_copy_nodes_rebased(const PtBvhNode* __restrict__ src, uint32_t n, uint32_t node_base, uint32_t tri_base,
+                                     PtBvhNode* __restrict__ dst)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    PtBvhNode nd = src[i];
+    int* c[2] = { &nd.c0, &nd.c1 };
+    for (int k = 0; k < 2; ++k) {
+        int v = *c[k];
+        if (v == (int)0x80000000) continue;
+        if (v >= 0) *c[k] = v + (int)node_base;
+        else { uint32_t code = ~(uint32_t)v; *c[k] = (int)~((((code >> 3) + tri_base) << 3) | (code & 7u)); }
+    }
+    dst[node_base + i] = nd;
+}
+
 inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
 struct DevMem {   // frees everything it allocated when it goes out of scope
@@ -603,6 +621,7 @@ int pt_tlas_build(PtContext* ctx, const PtInstance* instances, uint32_t n, PtTla
     PT_HIP_CHECK(hipEventRecord(ev0, st));
     PtTlas* t = new PtTlas();
     t->ctx = ctx; t->n = n; t->nodes = nullptr; t->leaf_inst = nullptr; t->inst = nullptr; t->shade_inst = nullptr;
+    t->pool_nodes = nullptr; t->pool_tris = nullptr; t->pool_node_count = 0;
     t->host_boxes.resize((size_t)n * 6); t->host_w2o.resize((size_t)n * 12);
     std::vector<PtDevInstance> di(n);
     t->host_o2w.resize((size_t)n * 12); t->host_custom.resize(n); t->shade_version = 0;
@@ -645,9 +664,7 @@ int pt_tlas_build(PtContext* ctx, const PtInstance* instances, uint32_t n, PtTla
         t->host_custom[i] = custom;
         di[i].q[3] = make_float4(lo[0], lo[1], lo[2], b->delta);
         di[i].q[4] = make_float4(hi[0], hi[1], hi[2], customf);
-        uint64_t pn = (uint64_t)(uintptr_t)b->nodes, pt = (uint64_t)(uintptr_t)b->tris;
-        uint32_t w[4] = { (uint32_t)pn, (uint32_t)(pn >> 32), (uint32_t)pt, (uint32_t)(pt >> 32) };
-        memcpy(&di[i].q[5], w, 16);
+        di[i].q[5] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // x = bits(root node of the BLAS in the pool), set below
     }
     float* boxes_dev = nullptr;
     hipError_t e = hipMalloc((void**)&boxes_dev, sizeof(float) * 6 * (size_t)n);
@@ -658,6 +675,30 @@ int pt_tlas_build(PtContext* ctx, const PtInstance* instances, uint32_t n, PtTla
     (void)hipFree(boxes_dev);
     if (rc) { delete t; return rc; }
     (void)hipFree(keys);
+    // pool: [TLAS nodes | nodes of every distinct BLAS], triangles of every distinct BLAS
+    {
+        std::vector<const PtBlas*> uniq;
+        std::vector<uint32_t> node_base, tri_base;
+        uint32_t nn = t->node_count, nt = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            const PtBlas* b = (const PtBlas*)(uintptr_t)instances[i].accelerationStructureReference;
+            size_t k = 0;
+            while (k < uniq.size() && uniq[k] != b) ++k;
+            if (k == uniq.size()) { uniq.push_back(b); node_base.push_back(nn); tri_base.push_back(nt); nn += b->node_count; nt += b->prim_count; }
+            float rootf; memcpy(&rootf, &node_base[k], 4);
+            di[i].q[5].x = rootf;
+        }
+        if (nt >= (1u << 28)) { pt_set_error("pt_tlas_build: more than 2^28 triangles in one TLAS"); pt_tlas_destroy(t); return PT_ERROR_LIMIT; }
+        e = hipMalloc((void**)&t->pool_nodes, sizeof(PtBvhNode) * (size_t)nn);
+        if (e == hipSuccess) e = hipMalloc((void**)&t->pool_tris, sizeof(float4) * 3 * (size_t)(nt ? nt : 1));
+        if (e == hipSuccess) e = hipMemcpyAsync(t->pool_nodes, t->nodes, sizeof(PtBvhNode) * t->node_count, hipMemcpyDeviceToDevice, st);
+        for (size_t k = 0; k < uniq.size() && e == hipSuccess; ++k) {
+            k_copy_nodes_rebased<<<div_up(uniq[k]->node_count, kBlock), kBlock, 0, st>>>(uniq[k]->nodes, uniq[k]->node_count, node_base[k], tri_base[k], t->pool_nodes);
+            e = hipMemcpyAsync(t->pool_tris + 3 * (size_t)tri_base[k], uniq[k]->tris, sizeof(float4) * 3 * (size_t)uniq[k]->prim_count, hipMemcpyDeviceToDevice, st);
+        }
+        if (e != hipSuccess) { pt_set_error("pt_tlas_build: %s", hipGetErrorString(e)); pt_tlas_destroy(t); return PT_ERROR_HIP; }
+        t->pool_node_count = nn;
+    }
     e = hipMalloc((void**)&t->inst, sizeof(PtDevInstance) * n);
     if (e == hipSuccess) e = hipMalloc((void**)&t->shade_inst, sizeof(PtDevShadeInstance) * n);
     if (e == hipSuccess) e = hipMemcpyAsync(t->inst, di.data(), sizeof(PtDevInstance) * n, hipMemcpyHostToDevice, st);
@@ -674,6 +715,7 @@ int pt_tlas_destroy(PtTlas* t)
 {
     if (!t) return PT_OK;
     (void)hipFree(t->nodes); (void)hipFree(t->leaf_inst); (void)hipFree(t->inst); (void)hipFree(t->shade_inst);
+    (void)hipFree(t->pool_nodes); (void)hipFree(t->pool_tris);
     delete t;
     return PT_OK;
 }

@@ -1,6 +1,7 @@
 // pt_capi.hip -- context, buffers, tables and error reporting of the C ABI (include/pt_hip.h).
 #include "pt_internal.h"
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 static thread_local char g_error[512] = "";
@@ -39,6 +40,7 @@ int pt_ctx_create(int device_id, void* hip_stream, PtContext** out)
     PtContext* c = new PtContext();
     c->device = device_id;
     c->num_cus = prop.multiProcessorCount;
+    if (const char* e = getenv("PT_HIP_TRAVERSAL")) c->traversal_mode = strcmp(e, "plain") == 0 ? 0 : 1;
     if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
     else {
         hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);

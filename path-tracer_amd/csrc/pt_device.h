@@ -8,6 +8,7 @@
 #include "pt_internal.h"
 
 #define PT_FMA(a, b, c) __builtin_fmaf((a), (b), (c))
+#define PT_DIR_EPS 8.271806125530277e-25f   // 2^-80
 
 struct PtRaySpace {
     float ox, oy, oz, dx, dy, dz;
@@ -17,8 +18,7 @@ struct PtRaySpace {
 
 __device__ __forceinline__ float pt_safe_rcp(float d)
 {
-    const float eps = 8.271806125530277e-25f; // 2^-80
-    float s = fabsf(d) > eps ? d : copysignf(eps, d);
+    float s = fabsf(d) > PT_DIR_EPS ? d : copysignf(PT_DIR_EPS, d);
     return 1.0f / s;
 }
 
@@ -27,6 +27,12 @@ __device__ __forceinline__ void pt_ray_space_init(PtRaySpace& r, float ox, float
     r.ox = ox; r.oy = oy; r.oz = oz; r.dx = dx; r.dy = dy; r.dz = dz;
     r.ix = pt_safe_rcp(dx); r.iy = pt_safe_rcp(dy); r.iz = pt_safe_rcp(dz);
     r.oox = ox * r.ix; r.ooy = oy * r.iy; r.ooz = oz * r.iz;
+}
+
+// A ray can hit triangles only if its dominant direction component is a usable divisor.
+__device__ __forceinline__ bool pt_ray_valid(float dx, float dy, float dz)
+{
+    return fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz)) > PT_DIR_EPS;
 }
 
 // Slab interval of a box: plane distance t(x) = fma(x, 1/d, -(o/d)).  The function is monotone in x,
@@ -41,48 +47,42 @@ __device__ __forceinline__ void pt_slab(const PtRaySpace& r, float lox, float lo
     tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
 }
 
-// Axis permutation and shear of the watertight ray/triangle test (Woop, Benthin, Wald 2013).
-struct PtWoop { int kx, ky, kz; float Sx, Sy, Sz; };
-
 __device__ __forceinline__ float pt_sel3(int k, float x, float y, float z) { return k == 0 ? x : (k == 1 ? y : z); }
 
-__device__ __forceinline__ bool pt_woop_init(PtWoop& w, float dx, float dy, float dz)
-{
-    int kz = 0;
-    float m = fabsf(dx);
-    if (fabsf(dy) > m) { kz = 1; m = fabsf(dy); }
-    if (fabsf(dz) > m) { kz = 2; }
-    int kx = kz == 2 ? 0 : kz + 1;
-    int ky = kx == 2 ? 0 : kx + 1;
-    float dkz = pt_sel3(kz, dx, dy, dz);
-    if (dkz < 0.0f) { int t = kx; kx = ky; ky = t; }
-    w.kx = kx; w.ky = ky; w.kz = kz;
-    w.Sx = pt_sel3(kx, dx, dy, dz) / dkz;
-    w.Sy = pt_sel3(ky, dx, dy, dz) / dkz;
-    w.Sz = 1.0f / dkz;
-    return dkz != 0.0f;
-}
-
-// Gated watertight test.  Returns true when the edge functions agree in sign, det != 0 and t lies
-// inside the slab interval of the triangle's own box padded by delta.
-__device__ __forceinline__ bool pt_tri_test(const PtRaySpace& r, const PtWoop& w, float delta,
+// Gated watertight ray/triangle test (Woop, Benthin, Wald 2013).  The axis permutation and shear are
+// recomputed from the ray on every call instead of being carried in registers: kz = dominant axis
+// (lowest index on ties), Sz = 1/d[kz] (the slab test's reciprocal), Sx = d[kx]*Sz, Sy = d[ky]*Sz.
+// Returns true when the edge functions agree in sign, det != 0 and t lies inside the slab interval of
+// the triangle's own box padded by delta.
+__device__ __forceinline__ bool pt_tri_test(const PtRaySpace& r, float delta,
                                             float v0x, float v0y, float v0z, float v1x, float v1y, float v1z,
                                             float v2x, float v2y, float v2z, float& t, float& u, float& v)
 {
+    int kz = 0;
+    float m = fabsf(r.dx);
+    if (fabsf(r.dy) > m) { kz = 1; m = fabsf(r.dy); }
+    if (fabsf(r.dz) > m) { kz = 2; }
+    int kx = kz == 2 ? 0 : kz + 1;
+    int ky = kx == 2 ? 0 : kx + 1;
+    if (pt_sel3(kz, r.dx, r.dy, r.dz) < 0.0f) { int s = kx; kx = ky; ky = s; }
+    const float Sz = pt_sel3(kz, r.ix, r.iy, r.iz);
+    const float Sx = pt_sel3(kx, r.dx, r.dy, r.dz) * Sz;
+    const float Sy = pt_sel3(ky, r.dx, r.dy, r.dz) * Sz;
+
     float Ax_ = v0x - r.ox, Ay_ = v0y - r.oy, Az_ = v0z - r.oz;
     float Bx_ = v1x - r.ox, By_ = v1y - r.oy, Bz_ = v1z - r.oz;
     float Cx_ = v2x - r.ox, Cy_ = v2y - r.oy, Cz_ = v2z - r.oz;
-    float Akz = pt_sel3(w.kz, Ax_, Ay_, Az_), Bkz = pt_sel3(w.kz, Bx_, By_, Bz_), Ckz = pt_sel3(w.kz, Cx_, Cy_, Cz_);
-    float Ax = PT_FMA(-w.Sx, Akz, pt_sel3(w.kx, Ax_, Ay_, Az_)), Ay = PT_FMA(-w.Sy, Akz, pt_sel3(w.ky, Ax_, Ay_, Az_));
-    float Bx = PT_FMA(-w.Sx, Bkz, pt_sel3(w.kx, Bx_, By_, Bz_)), By = PT_FMA(-w.Sy, Bkz, pt_sel3(w.ky, Bx_, By_, Bz_));
-    float Cx = PT_FMA(-w.Sx, Ckz, pt_sel3(w.kx, Cx_, Cy_, Cz_)), Cy = PT_FMA(-w.Sy, Ckz, pt_sel3(w.ky, Cx_, Cy_, Cz_));
+    float Akz = pt_sel3(kz, Ax_, Ay_, Az_), Bkz = pt_sel3(kz, Bx_, By_, Bz_), Ckz = pt_sel3(kz, Cx_, Cy_, Cz_);
+    float Ax = PT_FMA(-Sx, Akz, pt_sel3(kx, Ax_, Ay_, Az_)), Ay = PT_FMA(-Sy, Akz, pt_sel3(ky, Ax_, Ay_, Az_));
+    float Bx = PT_FMA(-Sx, Bkz, pt_sel3(kx, Bx_, By_, Bz_)), By = PT_FMA(-Sy, Bkz, pt_sel3(ky, Bx_, By_, Bz_));
+    float Cx = PT_FMA(-Sx, Ckz, pt_sel3(kx, Cx_, Cy_, Cz_)), Cy = PT_FMA(-Sy, Ckz, pt_sel3(ky, Cx_, Cy_, Cz_));
     float U = PT_FMA(Cx, By, -(Cy * Bx));
     float V = PT_FMA(Ax, Cy, -(Ay * Cx));
     float W = PT_FMA(Bx, Ay, -(By * Ax));
     if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) return false;
     float det = (U + V) + W;
     if (det == 0.0f) return false;
-    float Az = w.Sz * Akz, Bz = w.Sz * Bkz, Cz = w.Sz * Ckz;
+    float Az = Sz * Akz, Bz = Sz * Bkz, Cz = Sz * Ckz;
     float T = PT_FMA(W, Cz, PT_FMA(V, Bz, U * Az));
     float rcp = 1.0f / det;
     t = T * rcp; u = V * rcp; v = W * rcp;
@@ -94,8 +94,11 @@ __device__ __forceinline__ bool pt_tri_test(const PtRaySpace& r, const PtWoop& w
 
 struct PtHitRec { float t; uint32_t inst, prim; float u, v; };
 
+// One pool per TLAS: [TLAS nodes | nodes of every BLAS] with absolute child references, and the
+// triangle records of every BLAS; a node is four float4, a triangle three.
 struct PtTlasView {
-    const float4* nodes;          // 4 float4 per node
+    const float4* nodes;
+    const float4* tris;
     const uint32_t* leaf_inst;
     const PtDevInstance* inst;
 };
@@ -103,6 +106,7 @@ struct PtTlasView {
 #define PT_NODE_SENTINEL 0x7FFFFFFF
 #define PT_NODE_DONE 0x7FFFFFFE
 #define PT_NODE_EMPTY ((int)0x80000000)
+#define PT_NO_INSTANCE 0xFFFFFFFFu
 
 // Per-lane traversal stack: the first PT_LDS_STACK entries live in LDS ([entry][thread], one bank
 // per lane), deeper entries spill to a per-thread slice of a global buffer.
@@ -111,49 +115,61 @@ struct PtTlasView {
 
 struct PtStack {
     int* lds;          // &s_stack[0][threadIdx.x]
-    int* spill;        // per-thread slice of PT_SPILL_STACK ints
+    int* spill_base;   // spill buffer of the whole grid; this thread's slice is computed on demand
     int sp;
-    int lds_stride;    // blockDim.x
+    __device__ __forceinline__ int* spill_slot(int k) const
+    {
+        return spill_base + (size_t)(blockIdx.x * blockDim.x + threadIdx.x) * PT_SPILL_STACK + k;
+    }
     __device__ __forceinline__ void push(int v)
     {
-        if (sp < PT_LDS_STACK) lds[sp * lds_stride] = v;
-        else spill[sp - PT_LDS_STACK] = v;
+        if (sp < PT_LDS_STACK) lds[sp * (int)blockDim.x] = v;
+        else *spill_slot(sp - PT_LDS_STACK) = v;
         ++sp;
     }
     __device__ __forceinline__ int pop()
     {
         if (sp == 0) return PT_NODE_DONE;
         --sp;
-        return sp < PT_LDS_STACK ? lds[sp * lds_stride] : spill[sp - PT_LDS_STACK];
+        return sp < PT_LDS_STACK ? lds[sp * (int)blockDim.x] : *spill_slot(sp - PT_LDS_STACK);
     }
 };
+
+// Moves a world-space ray into the object space of instance record q (world->object rows q[0..2]).
+__device__ __forceinline__ void pt_to_object_space(const float4* __restrict__ q, const PtRaySpace& ws,
+                                                   float& ox, float& oy, float& oz, float& dx, float& dy, float& dz)
+{
+    const float4 r0 = q[0], r1 = q[1], r2 = q[2];
+    ox = PT_FMA(r0.x, ws.ox, PT_FMA(r0.y, ws.oy, PT_FMA(r0.z, ws.oz, r0.w)));
+    oy = PT_FMA(r1.x, ws.ox, PT_FMA(r1.y, ws.oy, PT_FMA(r1.z, ws.oz, r1.w)));
+    oz = PT_FMA(r2.x, ws.ox, PT_FMA(r2.y, ws.oy, PT_FMA(r2.z, ws.oz, r2.w)));
+    dx = PT_FMA(r0.x, ws.dx, PT_FMA(r0.y, ws.dy, r0.z * ws.dz));
+    dy = PT_FMA(r1.x, ws.dx, PT_FMA(r1.y, ws.dy, r1.z * ws.dz));
+    dz = PT_FMA(r2.x, ws.dx, PT_FMA(r2.y, ws.dy, r2.z * ws.dz));
+}
 
 // traceRayEXT(topLevelAS, gl_RayFlagsOpaqueEXT, 0xFF, 0, 0, 0, o, tmin, d, tmax, 0) of
 // shaders/ray_gen.rgen:54-65 with face culling disabled per instance
 // (source/top_level_acceleration_structure.cpp:28).
 // Closest hit = lexicographic minimum of (t, instance, primitive) over every triangle passing the
 // gated test with tmin < t < tmax and t inside the instance's world-box interval.
+// Plain form: one ray per lane from start to end (the wave-scheduled form is in pt_traverse_sched.h).
 __device__ __forceinline__ void pt_closest_hit(const PtTlasView& tl, PtStack& stk, float ox, float oy, float oz,
                                                float dx, float dy, float dz, float tmin, float tmax, PtHitRec& best)
 {
-    best.t = tmax; best.inst = 0xFFFFFFFFu; best.prim = 0xFFFFFFFFu; best.u = 0.0f; best.v = 0.0f;
+    best.t = tmax; best.inst = PT_NO_INSTANCE; best.prim = 0xFFFFFFFFu; best.u = 0.0f; best.v = 0.0f;
     PtRaySpace ws, cur;
     pt_ray_space_init(ws, ox, oy, oz, dx, dy, dz);
     cur = ws;
-    PtWoop woop; woop.kx = 0; woop.ky = 1; woop.kz = 2; woop.Sx = woop.Sy = woop.Sz = 0.0f;
-    const float4* nodes = tl.nodes;
-    const float4* tris = nullptr;
     float delta = 0.0f;
     float tlo = tmin, thi = tmax;   // closed interval handed to box tests in the current space
-    float tnI = 0.0f, tfI = 0.0f;
-    uint32_t cur_inst = 0;
-    bool in_blas = false;
+    uint32_t cur_inst = PT_NO_INSTANCE;
     stk.sp = 0;
     int node = 0;
     for (;;) {
         while ((unsigned)node < (unsigned)PT_NODE_DONE) {
-            const float4 n0 = nodes[4 * (size_t)node + 0], n1 = nodes[4 * (size_t)node + 1];
-            const float4 n2 = nodes[4 * (size_t)node + 2], n3 = nodes[4 * (size_t)node + 3];
+            const float4 n0 = tl.nodes[4 * (size_t)node + 0], n1 = tl.nodes[4 * (size_t)node + 1];
+            const float4 n2 = tl.nodes[4 * (size_t)node + 2], n3 = tl.nodes[4 * (size_t)node + 3];
             const int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
             float tn0, tf0, tn1, tf1;
             pt_slab(cur, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, tn0, tf0);
@@ -171,39 +187,28 @@ __device__ __forceinline__ void pt_closest_hit(const PtTlasView& tl, PtStack& st
         }
         if (node == PT_NODE_DONE) break;
         if (node == PT_NODE_SENTINEL) {      // all of the instance's BLAS visited: back to world space
-            in_blas = false; cur = ws; nodes = tl.nodes; tlo = tmin; thi = tmax;
+            cur_inst = PT_NO_INSTANCE; cur = ws; tlo = tmin; thi = tmax;
             node = stk.pop();
             continue;
         }
         const uint32_t code = ~(uint32_t)node;
         const uint32_t first = code >> 3, cnt = (code & 7u) + 1u;
-        if (!in_blas) {
+        if (cur_inst == PT_NO_INSTANCE) {
             const uint32_t ii = tl.leaf_inst[first];
             const float4* q = tl.inst[ii].q;
             const float4 blo = q[3], bhi = q[4];
             float a, b;
             pt_slab(ws, blo.x, blo.y, blo.z, bhi.x, bhi.y, bhi.z, a, b);
-            bool enter = (a <= b) && !(b < tmin) && !(a > tmax) && !(a > best.t);
-            if (enter) {
-                const float4 r0 = q[0], r1 = q[1], r2 = q[2];
-                float oox = PT_FMA(r0.x, ws.ox, PT_FMA(r0.y, ws.oy, PT_FMA(r0.z, ws.oz, r0.w)));
-                float ooy = PT_FMA(r1.x, ws.ox, PT_FMA(r1.y, ws.oy, PT_FMA(r1.z, ws.oz, r1.w)));
-                float ooz = PT_FMA(r2.x, ws.ox, PT_FMA(r2.y, ws.oy, PT_FMA(r2.z, ws.oz, r2.w)));
-                float odx = PT_FMA(r0.x, ws.dx, PT_FMA(r0.y, ws.dy, r0.z * ws.dz));
-                float ody = PT_FMA(r1.x, ws.dx, PT_FMA(r1.y, ws.dy, r1.z * ws.dz));
-                float odz = PT_FMA(r2.x, ws.dx, PT_FMA(r2.y, ws.dy, r2.z * ws.dz));
-                enter = pt_woop_init(woop, odx, ody, odz);
-                if (enter) {
+            if ((a <= b) && !(b < tmin) && !(a > tmax) && !(a > best.t)) {
+                float oox, ooy, ooz, odx, ody, odz;
+                pt_to_object_space(q, ws, oox, ooy, ooz, odx, ody, odz);
+                if (pt_ray_valid(odx, ody, odz)) {
                     pt_ray_space_init(cur, oox, ooy, ooz, odx, ody, odz);
-                    const float4 p = q[5];
-                    nodes = (const float4*)(((uint64_t)__float_as_uint(p.y) << 32) | __float_as_uint(p.x));
-                    tris = (const float4*)(((uint64_t)__float_as_uint(p.w) << 32) | __float_as_uint(p.z));
                     delta = blo.w;
-                    tnI = a; tfI = b; cur_inst = ii;
+                    cur_inst = ii;
                     tlo = fmaxf(tmin, a); thi = fminf(tmax, b);
-                    in_blas = true;
                     stk.push(PT_NODE_SENTINEL);
-                    node = 0;
+                    node = __float_as_int(q[5].x);
                     continue;
                 }
             }
@@ -211,11 +216,12 @@ __device__ __forceinline__ void pt_closest_hit(const PtTlasView& tl, PtStack& st
             continue;
         }
         for (uint32_t k = 0; k < cnt; ++k) {
-            const float4 a = tris[3 * (size_t)(first + k) + 0], b = tris[3 * (size_t)(first + k) + 1], c = tris[3 * (size_t)(first + k) + 2];
+            const float4 a = tl.tris[3 * (size_t)(first + k) + 0], b = tl.tris[3 * (size_t)(first + k) + 1], c = tl.tris[3 * (size_t)(first + k) + 2];
             float t, u, v;
-            if (pt_tri_test(cur, woop, delta, a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, t, u, v)) {
+            if (pt_tri_test(cur, delta, a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, t, u, v)) {
                 const uint32_t prim = __float_as_uint(c.y);
-                if (t > tmin && t < tmax && t >= tnI && t <= tfI) {
+                // tlo / thi fold the instance's world-box interval into (tmin, tmax)
+                if (t > tmin && t < tmax && t >= tlo && t <= thi) {
                     const bool closer = (t < best.t) || (t == best.t && (cur_inst < best.inst || (cur_inst == best.inst && prim < best.prim)));
                     if (closer) { best.t = t; best.inst = cur_inst; best.prim = prim; best.u = u; best.v = v; }
                 }

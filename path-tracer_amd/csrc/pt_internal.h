@@ -31,7 +31,7 @@ void pt_set_error(const char* fmt, ...);
 // ---- device-side records -------------------------------------------------------------------
 // Traversal view of one TLAS instance: six float4.
 //   [0..2] world->object rows; [3] = (box lo.xyz, delta); [4] = (box hi.xyz, bits(custom index));
-//   [5] = (nodes pointer lo/hi, triangles pointer lo/hi)
+//   [5] = (bits(root node index of the BLAS inside the TLAS pool), -, -, -)
 struct PtDevInstance { float4 q[6]; };
 // Shading view of one instance: the bindless chain blasInstances[custom] -> geometryNodes[first + 0] ->
 // materials[materialIndex] -> textures[albedoMapIndex] (closest_hit.rchit:57-59,75-79) is constant per
@@ -62,7 +62,10 @@ struct PtTlas {
     PtContext* ctx;
     uint32_t n;
     uint32_t node_count;
-    PtBvhNode* nodes;               // device
+    PtBvhNode* nodes;               // device: TLAS nodes alone (what pt_tlas_download returns)
+    PtBvhNode* pool_nodes;          // device: TLAS nodes followed by every distinct BLAS, references absolute
+    float4* pool_tris;              // device: triangle records of every distinct BLAS, 3 float4 each
+    uint32_t pool_node_count;
     uint32_t* leaf_inst;            // device, instance index per sorted slot
     PtDevInstance* inst;            // device, n
     PtDevShadeInstance* shade_inst; // device, n; rebuilt when the context's tables change
@@ -96,6 +99,7 @@ struct PtContext {
     bool own_stream = false;
     int num_cus = 0;
     uint64_t max_paths = 1ull << 25;
+    int traversal_mode = 1;   // 0: one batch of 64 rays per wave at a time; 1: wave-scheduled with ray replacement (PT_HIP_TRAVERSAL=plain|sched)
     // tables
     PtMaterial* materials = nullptr; uint32_t n_materials = 0;
     PtGeometryNode* geometry_nodes = nullptr; uint32_t n_geometry_nodes = 0;

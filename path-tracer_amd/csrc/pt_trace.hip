@@ -19,10 +19,14 @@
 // shard when one runs dry, so sizes stay on the device and a frame needs no host round trip.
 // Survivors of shard s go to shard s of the next queue, which therefore never overflows.
 #include "pt_device.h"
+#include "pt_traverse_sched.h"
 #include <string.h>
 
 namespace {
 
+#ifndef PT_INTERSECT_WAVES
+#define PT_INTERSECT_WAVES 4   // waves per SIMD the traversal kernels are compiled for
+#endif
 constexpr int kBlock = 256;
 constexpr int kShards = 64;
 constexpr int kCtrPad = 32;                              // uint32 slots per counter: one 128-byte line each
@@ -108,7 +112,7 @@ k_generate(uint32_t n_paths, uint32_t pixel0, uint32_t spp, uint32_t W, uint32_t
 // ------------------------------------------------------------------------------------------------
 // BY_ID: hit records go to hits[path id] (pt_intersect: caller's ray order) instead of the queue slot.
 template <bool BY_ID>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock, PT_INTERSECT_WAVES)
 k_intersect(PtTlasView tl, uint32_t* __restrict__ counters, uint32_t depth, uint32_t shard_cap,
             const float4* __restrict__ q0, const float4* __restrict__ q1, float tmin, float tmax,
             PtHit* __restrict__ hits, float* __restrict__ t_out, int* __restrict__ spill)
@@ -116,8 +120,7 @@ k_intersect(PtTlasView tl, uint32_t* __restrict__ counters, uint32_t depth, uint
     __shared__ int s_stack[PT_LDS_STACK][kBlock];
     PtStack stk;
     stk.lds = &s_stack[0][threadIdx.x];
-    stk.lds_stride = kBlock;
-    stk.spill = spill + (size_t)(blockIdx.x * blockDim.x + threadIdx.x) * PT_SPILL_STACK;
+    stk.spill_base = spill;
     for_each_batch(counters, CTR_WORK_INTERSECT, depth, shard_cap, [&](uint32_t i, bool valid, uint32_t) {
         if (valid) {
             const float4 o = q0[i], d = q1[i];
@@ -129,6 +132,23 @@ k_intersect(PtTlasView tl, uint32_t* __restrict__ counters, uint32_t depth, uint
             if (BY_ID && t_out) t_out[dst] = h.t;
         }
     });
+}
+
+// Same work, wave-scheduled: ray replacement + phase voting (pt_traverse_sched.h).
+template <bool BY_ID>
+__global__ void __launch_bounds__(kBlock, PT_INTERSECT_WAVES)
+k_intersect_sched(PtTlasView tl, uint32_t* __restrict__ counters, uint32_t depth, uint32_t shard_cap,
+                  const float4* __restrict__ q0, const float4* __restrict__ q1, float tmin, float tmax,
+                  PtHit* __restrict__ hits, float* __restrict__ t_out, int* __restrict__ spill)
+{
+    __shared__ int s_stack[PT_LDS_STACK][kBlock];
+    PtStack stk;
+    stk.lds = &s_stack[0][threadIdx.x];
+    stk.spill_base = spill;
+    PtSchedQueue Q;
+    Q.counters = counters; Q.shard_cap = shard_cap; Q.n_shards = kShards; Q.ctr_pad = kCtrPad;
+    Q.count_base = ctr_index(CTR_COUNT, depth, 0); Q.work_base = ctr_index(CTR_WORK_INTERSECT, depth, 0);
+    pt_traverse_sched<BY_ID>(tl, Q, stk, q0, q1, tmin, tmax, hits, t_out);
 }
 
 // rays given as packed float3 arrays (pt_intersect entry point): repack into the float4 streams
@@ -441,7 +461,7 @@ int ensure_shade_records(PtContext* ctx, const PtTlas* tlas_c)
 PtTlasView view_of(const PtTlas* t)
 {
     PtTlasView v;
-    v.nodes = (const float4*)t->nodes; v.leaf_inst = t->leaf_inst; v.inst = t->inst;
+    v.nodes = (const float4*)t->pool_nodes; v.tris = t->pool_tris; v.leaf_inst = t->leaf_inst; v.inst = t->inst;
     return v;
 }
 
@@ -462,9 +482,15 @@ int pt_intersect(PtContext* ctx, const PtTlas* tlas, uint32_t n, const float* or
     hipStream_t st = ctx->stream;
     PT_HIP_CHECK(hipMemsetAsync(w.counters, 0, sizeof(uint32_t) * kCounterWords, st));
     k_pack_rays<<<(n + kBlock - 1) / kBlock, kBlock, 0, st>>>(n, w.shard_cap, origins_dev, dirs_dev, w.q[0][0], w.q[0][1], w.counters);
-    int blocks = persistent_blocks(ctx, (const void*)k_intersect<true>);
-    k_intersect<true><<<blocks, kBlock, 0, st>>>(view_of(tlas), w.counters, 0, w.shard_cap, w.q[0][0], w.q[0][1],
-                                                 tmin, tmax, hits_dev, t_dev, w.spill);
+    if (ctx->traversal_mode == 0) {
+        int blocks = persistent_blocks(ctx, (const void*)k_intersect<true>);
+        k_intersect<true><<<blocks, kBlock, 0, st>>>(view_of(tlas), w.counters, 0, w.shard_cap, w.q[0][0], w.q[0][1],
+                                                     tmin, tmax, hits_dev, t_dev, w.spill);
+    } else {
+        int blocks = persistent_blocks(ctx, (const void*)k_intersect_sched<true>);
+        k_intersect_sched<true><<<blocks, kBlock, 0, st>>>(view_of(tlas), w.counters, 0, w.shard_cap, w.q[0][0], w.q[0][1],
+                                                           tmin, tmax, hits_dev, t_dev, w.spill);
+    }
     PT_HIP_CHECK(hipGetLastError());
     return PT_OK;
 }
@@ -493,7 +519,8 @@ int pt_trace(PtContext* ctx, const PtTlas* tlas, const float camera[32], uint32_
     hipStream_t st = ctx->stream;
     PT_HIP_CHECK(hipMemcpyAsync(w.cam, camera, sizeof(float) * 32, hipMemcpyHostToDevice, st));
     const PtTlasView tv = view_of(tlas);
-    const int blocks_i = persistent_blocks(ctx, (const void*)k_intersect<false>);
+    const int blocks_i = ctx->traversal_mode == 0 ? persistent_blocks(ctx, (const void*)k_intersect<false>)
+                                                  : persistent_blocks(ctx, (const void*)k_intersect_sched<false>);
     const int blocks_s = persistent_blocks(ctx, (const void*)k_shade);
     for (uint64_t p0 = 0; p0 < n_pixels; p0 += chunk_pixels) {
         const uint32_t np = (uint32_t)((n_pixels - p0) < chunk_pixels ? (n_pixels - p0) : chunk_pixels);
@@ -514,8 +541,12 @@ int pt_trace(PtContext* ctx, const PtTlas* tlas, const float camera[32], uint32_
                 ev_stop = ctx->ev_pool[ctx->ev_used + 1];
                 ctx->ev_used += 2;
             }
-            k_intersect<false><<<blocks_i, kBlock, 0, st>>>(tv, w.counters, d, w.shard_cap, w.q[a][0], w.q[a][1],
-                                                            0.001f, 10000.0f, w.hits, nullptr, w.spill);
+            if (ctx->traversal_mode == 0)
+                k_intersect<false><<<blocks_i, kBlock, 0, st>>>(tv, w.counters, d, w.shard_cap, w.q[a][0], w.q[a][1],
+                                                                0.001f, 10000.0f, w.hits, nullptr, w.spill);
+            else
+                k_intersect_sched<false><<<blocks_i, kBlock, 0, st>>>(tv, w.counters, d, w.shard_cap, w.q[a][0], w.q[a][1],
+                                                                      0.001f, 10000.0f, w.hits, nullptr, w.spill);
             if (ev_stop) PT_HIP_CHECK(hipEventRecord(ev_stop, st));
             k_shade<<<blocks_s, kBlock, 0, st>>>(tlas->shade_inst, d, max_depth, w.counters, w.shard_cap, w.hits,
                                                  w.q[a][0], w.q[a][1], w.q[a][2], w.q[a][3], w.q[b][0], w.q[b][1], w.q[b][2], w.q[b][3],

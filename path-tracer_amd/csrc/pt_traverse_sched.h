@@ -1,0 +1,218 @@
+// pt_traverse_sched.h -- wave-scheduled persistent traversal.
+//
+// Measured on incoherent bounces with one-ray-per-lane-until-the-batch-ends traversal: only 14-19 %
+// of the vector lanes do useful work (SQ_THREAD_CYCLES_VALU / 64 / SQ_ACTIVE_INST_VALU), because
+// (a) the 64 rays of a batch need very different numbers of steps and the wave runs as long as its
+//     longest ray, and
+// (b) lanes sit in different phases (box step, triangle test, instance entry) and every phase present
+//     in the wave is executed on every iteration, each at its own low lane count.
+// This kernel removes both:
+// (a) ray replacement: a lane whose ray has finished takes the next ray of the wave's private chunk
+//     (256 slots claimed with one atomic), so lanes stay populated until the queue is empty;
+// (b) phase voting: the wave executes ONE phase at a time -- the one its lanes vote for, for a few
+//     steps in a row -- and the other lanes wait, so the long phases (triangle test, instance entry)
+//     only run once enough lanes have accumulated in them.
+// Per-lane state is kept small (one ray space, the best hit, six scalars): the world-space ray is
+// re-read from the queue when a lane leaves an instance, and the triangle test rebuilds its axis
+// permutation from the ray, which keeps the kernel at six waves per SIMD.
+// The per-lane arithmetic (slab test, gated watertight triangle test, hit ordering) is the one in
+// pt_device.h, so results are bit-identical to the plain traversal.
+#pragma once
+#include "pt_device.h"
+
+#define PT_SCHED_CHUNK 256u        // queue slots a wave claims per atomic
+#define PT_SCHED_REFILL 12         // refill when at least this many lanes are idle
+#define PT_SCHED_LEAF_VOTES 20     // run the triangle phase once this many lanes wait in it ...
+#define PT_SCHED_ENTER_VOTES 10    // ... the instance-entry phase at this many ...
+#define PT_SCHED_NODE_MIN 24       // ... or when fewer than this many lanes want a box step
+#define PT_SCHED_NODE_STEPS 6      // box steps per vote while at least half the wave takes part
+#define PT_SCHED_LEAF_STEPS 4      // triangles per vote while enough lanes take part
+
+struct PtSchedQueue {              // the sharded queue of one bounce
+    uint32_t* counters;
+    uint32_t shard_cap, n_shards, ctr_pad;
+    size_t count_base, work_base;  // word offsets of the size / work counters of shard 0 at this depth
+};
+
+template <bool BY_ID>
+__device__ __forceinline__ void pt_traverse_sched(const PtTlasView& tl, const PtSchedQueue& Q, PtStack& stk,
+                                                  const float4* __restrict__ q0, const float4* __restrict__ q1,
+                                                  float tmin, float tmax, PtHit* __restrict__ hits, float* __restrict__ t_out)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+
+    // ---- wave-uniform work cursor
+    uint32_t shard_iter = 0, s = wave & (Q.n_shards - 1);
+    uint32_t n_s = Q.counters[Q.count_base + (size_t)s * Q.ctr_pad];
+    uint32_t wcur = 0, wend = 0;
+    bool drained = false;
+
+    // ---- per-lane traversal state
+    PtRaySpace cur;
+    PtHitRec best;
+    float delta = 0.0f, tlo = tmin, thi = tmax;
+    uint32_t cur_inst = PT_NO_INSTANCE, qi = 0;
+    int node = PT_NODE_DONE;       // PT_NODE_DONE: lane is idle
+    stk.sp = 0;
+    cur.ox = cur.oy = cur.oz = cur.dx = cur.dy = cur.dz = cur.ix = cur.iy = cur.iz = cur.oox = cur.ooy = cur.ooz = 0.0f;
+    best.t = tmax; best.inst = PT_NO_INSTANCE; best.prim = 0xFFFFFFFFu; best.u = best.v = 0.0f;
+
+    // Takes the next item for this lane after the current one is exhausted: pops until an inner node,
+    // a leaf or the end of the ray comes up; leaving an instance restores the world-space ray.
+    auto advance = [&](int v) {
+        for (;;) {
+            if (v == PT_NODE_SENTINEL) {
+                const float4 o = q0[qi], d = q1[qi];
+                pt_ray_space_init(cur, o.x, o.y, o.z, d.x, d.y, d.z);
+                cur_inst = PT_NO_INSTANCE; tlo = tmin; thi = tmax;
+                v = stk.pop();
+                continue;
+            }
+            if (v == PT_NODE_DONE) {
+                PtHit out; out.instance = best.inst; out.primitive = best.prim; out.u = best.u; out.v = best.v;
+                const uint32_t dst = BY_ID ? __float_as_uint(q1[qi].w) : qi;
+                hits[dst] = out;
+                if (BY_ID && t_out) t_out[dst] = best.t;
+            }
+            node = v;
+            return;
+        }
+    };
+
+    for (;;) {
+        // ------------------------------------------------------------------ refill idle lanes
+        unsigned long long idle = __ballot(node == PT_NODE_DONE);
+        if (!drained && (idle == ~0ull || __popcll(idle) >= PT_SCHED_REFILL)) {
+            while (idle) {
+                if (wcur == wend) {
+                    bool got = false;
+                    while (shard_iter < Q.n_shards) {
+                        if (n_s) {
+                            uint32_t* work = &Q.counters[Q.work_base + (size_t)s * Q.ctr_pad];
+                            if (__hip_atomic_load(work, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_s) {
+                                uint32_t base = 0;
+                                if (lane == 0) base = atomicAdd(work, PT_SCHED_CHUNK);
+                                base = __builtin_amdgcn_readfirstlane(base);
+                                if (base < n_s) {
+                                    wcur = s * Q.shard_cap + base;
+                                    wend = s * Q.shard_cap + (base + PT_SCHED_CHUNK < n_s ? base + PT_SCHED_CHUNK : n_s);
+                                    got = true;
+                                    break;
+                                }
+                            }
+                        }
+                        ++shard_iter;
+                        s = (wave + shard_iter) & (Q.n_shards - 1);
+                        n_s = Q.counters[Q.count_base + (size_t)s * Q.ctr_pad];
+                    }
+                    if (!got) { drained = true; break; }
+                }
+                const uint32_t n_idle = __popcll(idle), avail = wend - wcur;
+                const uint32_t take = n_idle < avail ? n_idle : avail;
+                const uint32_t rank = __popcll(idle & lt_mask);
+                if (node == PT_NODE_DONE && rank < take) {
+                    qi = wcur + rank;
+                    const float4 o = q0[qi], d = q1[qi];
+                    pt_ray_space_init(cur, o.x, o.y, o.z, d.x, d.y, d.z);
+                    cur_inst = PT_NO_INSTANCE; tlo = tmin; thi = tmax;
+                    best.t = tmax; best.inst = PT_NO_INSTANCE; best.prim = 0xFFFFFFFFu; best.u = best.v = 0.0f;
+                    stk.sp = 0;
+                    node = 0;
+                }
+                wcur += take;
+                idle = __ballot(node == PT_NODE_DONE);
+            }
+        }
+        bool want_node = (unsigned)node < (unsigned)PT_NODE_DONE;
+        bool want_leaf = node < 0 && cur_inst != PT_NO_INSTANCE;
+        const bool want_enter = node < 0 && cur_inst == PT_NO_INSTANCE;
+        int n_node = __popcll(__ballot(want_node));
+        int n_leaf = __popcll(__ballot(want_leaf));
+        const int n_enter = __popcll(__ballot(want_enter));
+        if (n_node + n_leaf + n_enter == 0) {
+            if (drained) break;
+            continue;
+        }
+        // ------------------------------------------------------------------ vote for one phase
+        int phase;   // 0 box step, 1 triangle, 2 instance entry
+        if (n_leaf >= PT_SCHED_LEAF_VOTES || (n_leaf > 0 && n_node < PT_SCHED_NODE_MIN && n_leaf >= n_enter)) phase = 1;
+        else if (n_enter >= PT_SCHED_ENTER_VOTES || (n_enter > 0 && n_node < PT_SCHED_NODE_MIN)) phase = 2;
+        else if (n_node > 0) phase = 0;
+        else phase = n_leaf >= n_enter ? 1 : 2;
+
+        if (phase == 0) {
+            int steps = PT_SCHED_NODE_STEPS;
+            do {
+                if (want_node) {
+                    const float4 n0 = tl.nodes[4 * (size_t)node + 0], n1 = tl.nodes[4 * (size_t)node + 1];
+                    const float4 n2 = tl.nodes[4 * (size_t)node + 2], n3 = tl.nodes[4 * (size_t)node + 3];
+                    const int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
+                    float tn0, tf0, tn1, tf1;
+                    pt_slab(cur, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, tn0, tf0);
+                    pt_slab(cur, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, tn1, tf1);
+                    const float hi = fminf(thi, best.t);
+                    const bool h0 = fmaxf(tn0, tlo) <= fminf(tf0, hi);
+                    const bool h1 = (c1 != PT_NODE_EMPTY) && fmaxf(tn1, tlo) <= fminf(tf1, hi);
+                    int next;
+                    if (h0 && h1) {
+                        const bool swap = tn1 < tn0;
+                        stk.push(swap ? c0 : c1);
+                        next = swap ? c1 : c0;
+                    } else if (h0) next = c0;
+                    else if (h1) next = c1;
+                    else next = stk.pop();
+                    if ((unsigned)next < (unsigned)PT_NODE_DONE) node = next; else advance(next);
+                    want_node = (unsigned)node < (unsigned)PT_NODE_DONE;
+                }
+                n_node = __popcll(__ballot(want_node));
+            } while (--steps > 0 && n_node >= 32);
+        } else if (phase == 1) {
+            int steps = PT_SCHED_LEAF_STEPS;
+            do {
+                if (want_leaf) {
+                    const uint32_t code = ~(uint32_t)node;
+                    const uint32_t pos = code >> 3;
+                    const float4 a = tl.tris[3 * (size_t)pos + 0], b = tl.tris[3 * (size_t)pos + 1], c = tl.tris[3 * (size_t)pos + 2];
+                    float t, u, v;
+                    if (pt_tri_test(cur, delta, a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, t, u, v)) {
+                        const uint32_t prim = __float_as_uint(c.y);
+                        if (t > tmin && t < tmax && t >= tlo && t <= thi) {
+                            const bool closer = (t < best.t) || (t == best.t && (cur_inst < best.inst || (cur_inst == best.inst && prim < best.prim)));
+                            if (closer) { best.t = t; best.inst = cur_inst; best.prim = prim; best.u = u; best.v = v; }
+                        }
+                    }
+                    // one triangle per step: first + 1, count - 1
+                    if (code & 7u) node = (int)~(code + 7u);
+                    else advance(stk.pop());
+                    want_leaf = node < 0 && cur_inst != PT_NO_INSTANCE;
+                }
+                n_leaf = __popcll(__ballot(want_leaf));
+            } while (--steps > 0 && n_leaf >= PT_SCHED_LEAF_VOTES / 2);
+        } else {
+            if (want_enter) {
+                const uint32_t ii = tl.leaf_inst[(~(uint32_t)node) >> 3];
+                const float4* q = tl.inst[ii].q;
+                const float4 blo = q[3], bhi = q[4];
+                float a, b;
+                pt_slab(cur, blo.x, blo.y, blo.z, bhi.x, bhi.y, bhi.z, a, b);
+                bool enter = (a <= b) && !(b < tmin) && !(a > tmax) && !(a > best.t);
+                if (enter) {
+                    float oox, ooy, ooz, odx, ody, odz;
+                    pt_to_object_space(q, cur, oox, ooy, ooz, odx, ody, odz);
+                    enter = pt_ray_valid(odx, ody, odz);
+                    if (enter) {
+                        pt_ray_space_init(cur, oox, ooy, ooz, odx, ody, odz);
+                        delta = blo.w;
+                        cur_inst = ii;
+                        tlo = fmaxf(tmin, a); thi = fminf(tmax, b);
+                        stk.push(PT_NODE_SENTINEL);
+                        node = __float_as_int(q[5].x);
+                    }
+                }
+                if (!enter) advance(stk.pop());
+            }
+        }
+    }
+}

@@ -14,7 +14,7 @@ import numpy as np
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libpt_hip.so")
+LIB_PATH = os.environ.get("PT_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libpt_hip.so")
 
 PT_MAX_DEPTH = 64
 SEED_SAMPLE_INDEX, SEED_CLOCK = 0, 1
