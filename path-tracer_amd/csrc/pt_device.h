@@ -94,8 +94,8 @@ __device__ __forceinline__ bool pt_tri_test(const PtRaySpace& r, float delta,
 
 struct PtHitRec { float t; uint32_t inst, prim; float u, v; };
 
-// One pool per TLAS: [TLAS nodes | nodes of every BLAS] with absolute child references, and the
-// triangle records of every BLAS; a node is four float4, a triangle three.
+// One pool per TLAS: [wide nodes of the TLAS | wide nodes of every BLAS] with absolute child
+// references, and the triangle records of every BLAS; a node is four float4, a triangle three.
 struct PtTlasView {
     const float4* nodes;
     const float4* tris;
@@ -110,8 +110,6 @@ struct PtTlasView {
 
 // Per-lane traversal stack: the first PT_LDS_STACK entries live in LDS ([entry][thread], one bank
 // per lane), deeper entries spill to a per-thread slice of a global buffer.
-#define PT_LDS_STACK 24
-#define PT_SPILL_STACK 104
 
 struct PtStack {
     int* lds;          // &s_stack[0][threadIdx.x]
@@ -134,6 +132,46 @@ struct PtStack {
         return sp < PT_LDS_STACK ? lds[sp * (int)blockDim.x] : *spill_slot(sp - PT_LDS_STACK);
     }
 };
+
+// One step through a 64-byte 4-wide node with child boxes quantised to 8 bits on the node's own
+// grid: (origin.xyz, exponents) (child[0..3]) (lo.x lo.y lo.z hi.x words) (hi.y hi.z words, -, -);
+// byte k of each word belongs to child k and a plane is fma(byte, 2^exponent, origin).
+// Continues with the nearest child that the ray interval [tlo, hi] overlaps and pushes the others
+// so that nearer ones are popped first; returns the next item (a pop if nothing was hit).
+__device__ __forceinline__ int pt_wide_step(const PtRaySpace& r, const float4* __restrict__ nodes, int node,
+                                            float tlo, float hi, PtStack& stk)
+{
+    const float4 h0 = nodes[4 * (size_t)node + 0], h1 = nodes[4 * (size_t)node + 1];
+    const float4 h2 = nodes[4 * (size_t)node + 2], h3 = nodes[4 * (size_t)node + 3];
+    const uint32_t exps = __float_as_uint(h0.w);
+    const float sx = __uint_as_float((exps & 255u) << 23);
+    const float sy = __uint_as_float(((exps >> 8) & 255u) << 23);
+    const float sz = __uint_as_float(((exps >> 16) & 255u) << 23);
+    const uint32_t Lx = __float_as_uint(h2.x), Ly = __float_as_uint(h2.y), Lz = __float_as_uint(h2.z);
+    const uint32_t Hx = __float_as_uint(h2.w), Hy = __float_as_uint(h3.x), Hz = __float_as_uint(h3.y);
+    const int ref_in[4] = { __float_as_int(h1.x), __float_as_int(h1.y), __float_as_int(h1.z), __float_as_int(h1.w) };
+    const float inf = __builtin_inff();
+    float tn[4]; int ref[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float lox = PT_FMA((float)((Lx >> (8 * k)) & 255u), sx, h0.x), hix = PT_FMA((float)((Hx >> (8 * k)) & 255u), sx, h0.x);
+        const float loy = PT_FMA((float)((Ly >> (8 * k)) & 255u), sy, h0.y), hiy = PT_FMA((float)((Hy >> (8 * k)) & 255u), sy, h0.y);
+        const float loz = PT_FMA((float)((Lz >> (8 * k)) & 255u), sz, h0.z), hiz = PT_FMA((float)((Hz >> (8 * k)) & 255u), sz, h0.z);
+        float a, b;
+        pt_slab(r, lox, loy, loz, hix, hiy, hiz, a, b);
+        const bool hit = (ref_in[k] != PT_NODE_EMPTY) && fmaxf(a, tlo) <= fminf(b, hi);
+        tn[k] = hit ? a : inf;
+        ref[k] = ref_in[k];
+    }
+#define PT_CSWAP(i, j) { const bool sw = tn[j] < tn[i]; const float ta = sw ? tn[j] : tn[i], tb = sw ? tn[i] : tn[j]; \
+                         const int ra = sw ? ref[j] : ref[i], rb = sw ? ref[i] : ref[j]; tn[i] = ta; tn[j] = tb; ref[i] = ra; ref[j] = rb; }
+    PT_CSWAP(0, 1) PT_CSWAP(2, 3) PT_CSWAP(0, 2) PT_CSWAP(1, 3) PT_CSWAP(1, 2)
+#undef PT_CSWAP
+    if (tn[3] < inf) stk.push(ref[3]);
+    if (tn[2] < inf) stk.push(ref[2]);
+    if (tn[1] < inf) stk.push(ref[1]);
+    return tn[0] < inf ? ref[0] : stk.pop();
+}
 
 // Moves a world-space ray into the object space of instance record q (world->object rows q[0..2]).
 __device__ __forceinline__ void pt_to_object_space(const float4* __restrict__ q, const PtRaySpace& ws,
@@ -167,24 +205,8 @@ __device__ __forceinline__ void pt_closest_hit(const PtTlasView& tl, PtStack& st
     stk.sp = 0;
     int node = 0;
     for (;;) {
-        while ((unsigned)node < (unsigned)PT_NODE_DONE) {
-            const float4 n0 = tl.nodes[4 * (size_t)node + 0], n1 = tl.nodes[4 * (size_t)node + 1];
-            const float4 n2 = tl.nodes[4 * (size_t)node + 2], n3 = tl.nodes[4 * (size_t)node + 3];
-            const int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
-            float tn0, tf0, tn1, tf1;
-            pt_slab(cur, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, tn0, tf0);
-            pt_slab(cur, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, tn1, tf1);
-            const float hi = fminf(thi, best.t);
-            const bool h0 = fmaxf(tn0, tlo) <= fminf(tf0, hi);
-            const bool h1 = (c1 != PT_NODE_EMPTY) && fmaxf(tn1, tlo) <= fminf(tf1, hi);
-            if (h0 && h1) {
-                const bool swap = tn1 < tn0;
-                stk.push(swap ? c0 : c1);
-                node = swap ? c1 : c0;
-            } else if (h0) node = c0;
-            else if (h1) node = c1;
-            else node = stk.pop();
-        }
+        while ((unsigned)node < (unsigned)PT_NODE_DONE)
+            node = pt_wide_step(cur, tl.nodes, node, tlo, fminf(thi, best.t), stk);
         if (node == PT_NODE_DONE) break;
         if (node == PT_NODE_SENTINEL) {      // all of the instance's BLAS visited: back to world space
             cur_inst = PT_NO_INSTANCE; cur = ws; tlo = tmin; thi = tmax;

@@ -63,7 +63,7 @@ struct PtTlas {
     uint32_t n;
     uint32_t node_count;
     PtBvhNode* nodes;               // device: TLAS nodes alone (what pt_tlas_download returns)
-    PtBvhNode* pool_nodes;          // device: TLAS nodes followed by every distinct BLAS, references absolute
+    void* pool_nodes;               // device: 64-byte 4-wide quantised nodes, TLAS first then every distinct BLAS, references absolute
     float4* pool_tris;              // device: triangle records of every distinct BLAS, 3 float4 each
     uint32_t pool_node_count;
     uint32_t* leaf_inst;            // device, instance index per sorted slot
@@ -92,6 +92,10 @@ struct PtWorkspace {
     int* spill = nullptr;              // traversal stack overflow, PT_SPILL_STACK ints per persistent thread
     uint64_t spill_threads = 0;
 };
+
+// Per-lane traversal stack capacity: entries in LDS, then entries in a per-thread global slice.
+#define PT_LDS_STACK 24
+#define PT_SPILL_STACK 104
 
 struct PtContext {
     int device = 0;

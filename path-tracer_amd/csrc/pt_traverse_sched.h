@@ -146,23 +146,7 @@ __device__ __forceinline__ void pt_traverse_sched(const PtTlasView& tl, const Pt
             int steps = PT_SCHED_NODE_STEPS;
             do {
                 if (want_node) {
-                    const float4 n0 = tl.nodes[4 * (size_t)node + 0], n1 = tl.nodes[4 * (size_t)node + 1];
-                    const float4 n2 = tl.nodes[4 * (size_t)node + 2], n3 = tl.nodes[4 * (size_t)node + 3];
-                    const int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
-                    float tn0, tf0, tn1, tf1;
-                    pt_slab(cur, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, tn0, tf0);
-                    pt_slab(cur, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, tn1, tf1);
-                    const float hi = fminf(thi, best.t);
-                    const bool h0 = fmaxf(tn0, tlo) <= fminf(tf0, hi);
-                    const bool h1 = (c1 != PT_NODE_EMPTY) && fmaxf(tn1, tlo) <= fminf(tf1, hi);
-                    int next;
-                    if (h0 && h1) {
-                        const bool swap = tn1 < tn0;
-                        stk.push(swap ? c0 : c1);
-                        next = swap ? c1 : c0;
-                    } else if (h0) next = c0;
-                    else if (h1) next = c1;
-                    else next = stk.pop();
+                    const int next = pt_wide_step(cur, tl.nodes, node, tlo, fminf(thi, best.t), stk);
                     if ((unsigned)next < (unsigned)PT_NODE_DONE) node = next; else advance(next);
                     want_node = (unsigned)node < (unsigned)PT_NODE_DONE;
                 }
