@@ -10,6 +10,7 @@
 // scheduling; nothing here hands data between workgroups inside a launch except through
 // commutative integer atomics read by a later kernel.
 #include "pt_internal.h"
+#include "pt_wide.h"
 #include <math.h>
 #include <string.h>
 #include <limits>
@@ -572,110 +573,6 @@ int pt_blas_download(const PtBlas* b, PtBvhNode* nodes, uint32_t* leaf_prims, ui
     return PT_OK;
 }
 
-// ---------------------------------------------------------------------------------------------
-// Traversal layout: 4-wide nodes with child boxes quantised to 8 bits on a per-node grid (64 bytes
-// for four children instead of 64 bytes for two).  The traversal kernels are bound by the number of
-// 16-byte-per-lane loads the texture path has to serve for scattered node fetches, so bytes per
-// child are what counts.  A wide node is a node of the canonical binary tree at even depth; its
-// entries are its grandchildren (or a child that is a leaf).  Quantisation only ever grows a box
-// (checked with the same fma the kernels use to expand it), so the set of triangles a ray is tested
-// against can grow but the closest hit cannot change.
-struct Wide4 {
-    float origin[3];
-    uint32_t exps;          // biased binary32 exponents of the grid step: x | y << 8 | z << 16
-    int32_t child[4];       // >= 0 wide node, < 0 leaf (~c = first << 3 | count - 1), INT32_MIN empty
-    uint32_t q[6];          // lo.x, lo.y, lo.z, hi.x, hi.y, hi.z; byte k of each word belongs to child k
-    uint32_t pad[2];
-};
-static_assert(sizeof(Wide4) == 64, "wide node must be 64 bytes");
-
-static inline float grid_plane(uint32_t q, uint32_t exp_byte, float origin)
-{
-    uint32_t bits = exp_byte << 23; float scale; memcpy(&scale, &bits, 4);
-    return __builtin_fmaf((float)q, scale, origin);
-}
-
-// Collapses one binary BVH (host copy) into wide nodes appended to `out`.  Inner references are
-// rebased by the position of the first appended node, leaf references by tri_base.  Returns the
-// depth of the wide tree (a single node has depth 1).
-static uint32_t collapse_to_wide(const std::vector<PtBvhNode>& n2, uint32_t tri_base, std::vector<Wide4>& out)
-{
-    const int32_t EMPTY = std::numeric_limits<int32_t>::min();
-    const uint32_t base = (uint32_t)out.size();
-    std::vector<uint32_t> todo { 0 };            // binary nodes that become wide nodes, in breadth-first order
-    std::vector<int32_t> wide_of(n2.size(), -1);
-    std::vector<uint32_t> depth_of { 1 };
-    uint32_t max_depth = 1;
-    wide_of[0] = 0;
-    for (size_t head = 0; head < todo.size(); ++head) {
-        const PtBvhNode& nd = n2[todo[head]];
-        struct Entry { int32_t ref; float lo[3], hi[3]; };
-        Entry ent[4]; int ne = 0;
-        auto add = [&](int32_t ref, const float* lo, const float* hi) { ent[ne].ref = ref; for (int k = 0; k < 3; ++k) { ent[ne].lo[k] = lo[k]; ent[ne].hi[k] = hi[k]; } ++ne; };
-        const int32_t cs[2] = { nd.c0, nd.c1 };
-        const float* clo[2] = { nd.lo0, nd.lo1 }; const float* chi[2] = { nd.hi0, nd.hi1 };
-        for (int s = 0; s < 2; ++s) {
-            if (cs[s] == EMPTY) continue;
-            if (cs[s] < 0) { add(cs[s], clo[s], chi[s]); continue; }
-            const PtBvhNode& ch = n2[cs[s]];
-            if (ch.c0 != EMPTY) add(ch.c0, ch.lo0, ch.hi0);
-            if (ch.c1 != EMPTY) add(ch.c1, ch.lo1, ch.hi1);
-        }
-        Wide4 w; memset(&w, 0, sizeof w);
-        float lo[3], hi[3];
-        for (int k = 0; k < 3; ++k) { lo[k] = ent[0].lo[k]; hi[k] = ent[0].hi[k]; }
-        for (int e = 1; e < ne; ++e) for (int k = 0; k < 3; ++k) { lo[k] = fminf(lo[k], ent[e].lo[k]); hi[k] = fmaxf(hi[k], ent[e].hi[k]); }
-        uint32_t ex[3];
-        for (int k = 0; k < 3; ++k) {
-            w.origin[k] = lo[k];
-            // smallest power-of-two step with 255 steps covering the extent; grown until every plane fits
-            int e2; float ext = hi[k] - lo[k];
-            if (!(ext > 0.0f)) e2 = -126; else { (void)frexpf(ext / 255.0f, &e2); }
-            int eb = e2 + 127; if (eb < 1) eb = 1; if (eb > 254) eb = 254;
-            for (;; ++eb) {
-                bool ok = true;
-                for (int e = 0; e < ne && ok; ++e) {
-                    uint32_t bits = (uint32_t)eb << 23; float scale; memcpy(&scale, &bits, 4);
-                    double qh = ceil(((double)ent[e].hi[k] - (double)lo[k]) / (double)scale);
-                    if (qh > 255.0) ok = false;
-                    else { uint32_t q = (uint32_t)(qh < 0 ? 0 : qh); while (q <= 255 && grid_plane(q, (uint32_t)eb, lo[k]) < ent[e].hi[k]) ++q; if (q > 255) ok = false; }
-                }
-                if (ok || eb >= 254) break;
-            }
-            ex[k] = (uint32_t)eb;
-        }
-        w.exps = ex[0] | (ex[1] << 8) | (ex[2] << 16);
-        for (int e = 0; e < 4; ++e) w.child[e] = EMPTY;
-        for (int e = 0; e < ne; ++e) {
-            for (int k = 0; k < 3; ++k) {
-                uint32_t bits = ex[k] << 23; float scale; memcpy(&scale, &bits, 4);
-                double ql = floor(((double)ent[e].lo[k] - (double)lo[k]) / (double)scale);
-                uint32_t q_lo = (uint32_t)(ql < 0 ? 0 : (ql > 255 ? 255 : ql));
-                while (q_lo > 0 && grid_plane(q_lo, ex[k], lo[k]) > ent[e].lo[k]) --q_lo;
-                double qh = ceil(((double)ent[e].hi[k] - (double)lo[k]) / (double)scale);
-                uint32_t q_hi = (uint32_t)(qh < 0 ? 0 : (qh > 255 ? 255 : qh));
-                while (q_hi < 255 && grid_plane(q_hi, ex[k], lo[k]) < ent[e].hi[k]) ++q_hi;
-                w.q[k] |= q_lo << (8 * e);
-                w.q[3 + k] |= q_hi << (8 * e);
-            }
-            int32_t ref = ent[e].ref;
-            if (ref >= 0) {
-                if (wide_of[ref] < 0) {
-                    wide_of[ref] = (int32_t)todo.size(); todo.push_back((uint32_t)ref);
-                    depth_of.push_back(depth_of[head] + 1);
-                    max_depth = depth_of[head] + 1 > max_depth ? depth_of[head] + 1 : max_depth;
-                }
-                w.child[e] = (int32_t)(base + (uint32_t)wide_of[ref]);
-            } else {
-                uint32_t code = ~(uint32_t)ref;
-                w.child[e] = (int32_t)~((((code >> 3) + tri_base) << 3) | (code & 7u));
-            }
-        }
-        out.push_back(w);
-    }
-    return max_depth;
-}
-
 // Inverse of a row-major 3x4 affine transform in binary64 by cofactors, rounded once to binary32:
 // the world->object matrix the driver would expose as gl_WorldToObjectEXT.
 static void invert_transform(const float m[12], float w[12])
@@ -775,17 +672,17 @@ int pt_tlas_build(PtContext* ctx, const PtInstance* instances, uint32_t n, PtTla
             blas_of_inst[i] = (uint32_t)k;
         }
         if (nt >= (1u << 28)) { pt_set_error("pt_tlas_build: more than 2^28 triangles in one TLAS"); pt_tlas_destroy(t); return PT_ERROR_LIMIT; }
-        std::vector<Wide4> wide;
+        std::vector<PtWide4> wide;
         std::vector<PtBvhNode> host2(t->node_count);
         e = hipMemcpy(host2.data(), t->nodes, sizeof(PtBvhNode) * t->node_count, hipMemcpyDeviceToHost);
         uint32_t depth_tlas = 0, depth_blas = 0;
-        if (e == hipSuccess) depth_tlas = collapse_to_wide(host2, 0, wide);
+        if (e == hipSuccess) depth_tlas = pt_collapse_to_wide(host2, 0, wide);
         std::vector<uint32_t> root_of(uniq.size());
         for (size_t k = 0; k < uniq.size() && e == hipSuccess; ++k) {
             host2.resize(uniq[k]->node_count);
             e = hipMemcpy(host2.data(), uniq[k]->nodes, sizeof(PtBvhNode) * uniq[k]->node_count, hipMemcpyDeviceToHost);
             root_of[k] = (uint32_t)wide.size();
-            if (e == hipSuccess) { const uint32_t d = collapse_to_wide(host2, tri_base[k], wide); depth_blas = d > depth_blas ? d : depth_blas; }
+            if (e == hipSuccess) { const uint32_t d = pt_collapse_to_wide(host2, tri_base[k], wide); depth_blas = d > depth_blas ? d : depth_blas; }
         }
         // a step pushes at most three references and an instance entry one
         if (e == hipSuccess && 3 * depth_tlas + 1 + 3 * depth_blas > PT_LDS_STACK + PT_SPILL_STACK) {
@@ -793,9 +690,9 @@ int pt_tlas_build(PtContext* ctx, const PtInstance* instances, uint32_t n, PtTla
             pt_tlas_destroy(t); return PT_ERROR_LIMIT;
         }
         for (uint32_t i = 0; i < n; ++i) { float rootf; memcpy(&rootf, &root_of[blas_of_inst[i]], 4); di[i].q[5].x = rootf; }
-        if (e == hipSuccess) e = hipMalloc((void**)&t->pool_nodes, sizeof(Wide4) * wide.size());
+        if (e == hipSuccess) e = hipMalloc((void**)&t->pool_nodes, sizeof(PtWide4) * wide.size());
         if (e == hipSuccess) e = hipMalloc((void**)&t->pool_tris, sizeof(float4) * 3 * (size_t)(nt ? nt : 1));
-        if (e == hipSuccess) e = hipMemcpyAsync(t->pool_nodes, wide.data(), sizeof(Wide4) * wide.size(), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(t->pool_nodes, wide.data(), sizeof(PtWide4) * wide.size(), hipMemcpyHostToDevice, st);
         for (size_t k = 0; k < uniq.size() && e == hipSuccess; ++k)
             e = hipMemcpyAsync(t->pool_tris + 3 * (size_t)tri_base[k], uniq[k]->tris, sizeof(float4) * 3 * (size_t)uniq[k]->prim_count, hipMemcpyDeviceToDevice, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);   // `wide` is host memory that goes out of scope

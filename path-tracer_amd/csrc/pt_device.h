@@ -94,6 +94,22 @@ __device__ __forceinline__ bool pt_tri_test(const PtRaySpace& r, float delta,
 
 struct PtHitRec { float t; uint32_t inst, prim; float u, v; };
 
+// Keeps the lexicographic minimum of (t, instance, primitive).  The order is evaluated without
+// short-circuits into one predicate and applied with selects: written as nested branches, the
+// compiler (ROCm 7.2 clang, gfx950) kept two copies of the record and updated only one of them
+// on the tie path, so a tie won by the later candidate returned stale fields.
+__device__ __forceinline__ void pt_hit_update(PtHitRec& best, float t, uint32_t inst, uint32_t prim, float u, float v)
+{
+    const unsigned long long id = ((unsigned long long)inst << 32) | prim;
+    const unsigned long long best_id = ((unsigned long long)best.inst << 32) | best.prim;
+    const bool closer = (t < best.t) | ((t == best.t) & (id < best_id));
+    best.t = closer ? t : best.t;
+    best.inst = closer ? inst : best.inst;
+    best.prim = closer ? prim : best.prim;
+    best.u = closer ? u : best.u;
+    best.v = closer ? v : best.v;
+}
+
 // One pool per TLAS: [wide nodes of the TLAS | wide nodes of every BLAS] with absolute child
 // references, and the triangle records of every BLAS; a node is four float4, a triangle three.
 struct PtTlasView {
@@ -109,27 +125,49 @@ struct PtTlasView {
 #define PT_NO_INSTANCE 0xFFFFFFFFu
 
 // Per-lane traversal stack: the first PT_LDS_STACK entries live in LDS ([entry][thread], one bank
-// per lane), deeper entries spill to a per-thread slice of a global buffer.
+// per lane), deeper entries spill to a per-thread slice of a global buffer.  The traversal kernels
+// run with PT_TRAVERSE_BLOCK threads per block, which makes the LDS stride a constant.
+#define PT_TRAVERSE_BLOCK 256
+typedef __attribute__((address_space(3))) int pt_lds_int;
 
 struct PtStack {
-    int* lds;          // &s_stack[0][threadIdx.x]
+    pt_lds_int* lds;   // &s_stack[0][threadIdx.x]
     int* spill_base;   // spill buffer of the whole grid; this thread's slice is computed on demand
     int sp;
     __device__ __forceinline__ int* spill_slot(int k) const
     {
-        return spill_base + (size_t)(blockIdx.x * blockDim.x + threadIdx.x) * PT_SPILL_STACK + k;
+        return spill_base + (size_t)(blockIdx.x * PT_TRAVERSE_BLOCK + threadIdx.x) * PT_SPILL_STACK + k;
     }
     __device__ __forceinline__ void push(int v)
     {
-        if (sp < PT_LDS_STACK) lds[sp * (int)blockDim.x] = v;
+        if (sp < PT_LDS_STACK) lds[sp * PT_TRAVERSE_BLOCK] = v;
         else *spill_slot(sp - PT_LDS_STACK) = v;
         ++sp;
+    }
+    // Pushes r[m], ..., r[1] in this order (m in 0..3) so that r[1] is popped first.
+    __device__ __forceinline__ void push_far_to_near(int r1, int r2, int r3, int m)
+    {
+        if (sp + 3 <= PT_LDS_STACK) {
+            // r[j] belongs at sp + m - j; an entry beyond m lands on slot sp first and is
+            // overwritten by r[m], or stays above the new top when m == 0
+            lds[(sp + max(m - 3, 0)) * PT_TRAVERSE_BLOCK] = r3;
+            lds[(sp + max(m - 2, 0)) * PT_TRAVERSE_BLOCK] = r2;
+            lds[(sp + max(m - 1, 0)) * PT_TRAVERSE_BLOCK] = r1;
+            sp += m;
+        } else {
+            if (m > 2) push(r3);
+            if (m > 1) push(r2);
+            if (m > 0) push(r1);
+        }
     }
     __device__ __forceinline__ int pop()
     {
         if (sp == 0) return PT_NODE_DONE;
         --sp;
-        return sp < PT_LDS_STACK ? lds[sp * (int)blockDim.x] : *spill_slot(sp - PT_LDS_STACK);
+        int v;
+        if (sp < PT_LDS_STACK) v = lds[sp * PT_TRAVERSE_BLOCK];
+        else v = *spill_slot(sp - PT_LDS_STACK);
+        return v;
     }
 };
 
@@ -167,9 +205,8 @@ __device__ __forceinline__ int pt_wide_step(const PtRaySpace& r, const float4* _
                          const int ra = sw ? ref[j] : ref[i], rb = sw ? ref[i] : ref[j]; tn[i] = ta; tn[j] = tb; ref[i] = ra; ref[j] = rb; }
     PT_CSWAP(0, 1) PT_CSWAP(2, 3) PT_CSWAP(0, 2) PT_CSWAP(1, 3) PT_CSWAP(1, 2)
 #undef PT_CSWAP
-    if (tn[3] < inf) stk.push(ref[3]);
-    if (tn[2] < inf) stk.push(ref[2]);
-    if (tn[1] < inf) stk.push(ref[1]);
+    const int m = (tn[1] < inf ? 1 : 0) + (tn[2] < inf ? 1 : 0) + (tn[3] < inf ? 1 : 0);
+    stk.push_far_to_near(ref[1], ref[2], ref[3], m);
     return tn[0] < inf ? ref[0] : stk.pop();
 }
 
@@ -244,8 +281,7 @@ __device__ __forceinline__ void pt_closest_hit(const PtTlasView& tl, PtStack& st
                 const uint32_t prim = __float_as_uint(c.y);
                 // tlo / thi fold the instance's world-box interval into (tmin, tmax)
                 if (t > tmin && t < tmax && t >= tlo && t <= thi) {
-                    const bool closer = (t < best.t) || (t == best.t && (cur_inst < best.inst || (cur_inst == best.inst && prim < best.prim)));
-                    if (closer) { best.t = t; best.inst = cur_inst; best.prim = prim; best.u = u; best.v = v; }
+                    pt_hit_update(best, t, cur_inst, prim, u, v);
                 }
             }
         }

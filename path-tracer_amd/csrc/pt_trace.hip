@@ -28,6 +28,7 @@ namespace {
 #define PT_INTERSECT_WAVES 4   // waves per SIMD the traversal kernels are compiled for
 #endif
 constexpr int kBlock = 256;
+static_assert(kBlock == PT_TRAVERSE_BLOCK, "traversal stack stride");
 constexpr int kShards = 64;
 constexpr int kCtrPad = 32;                              // uint32 slots per counter: one 128-byte line each
 constexpr int kCtrPerKind = (PT_MAX_DEPTH + 1) * kShards;
@@ -119,7 +120,7 @@ k_intersect(PtTlasView tl, uint32_t* __restrict__ counters, uint32_t depth, uint
 {
     __shared__ int s_stack[PT_LDS_STACK][kBlock];
     PtStack stk;
-    stk.lds = &s_stack[0][threadIdx.x];
+    stk.lds = (pt_lds_int*)&s_stack[0][threadIdx.x];
     stk.spill_base = spill;
     for_each_batch(counters, CTR_WORK_INTERSECT, depth, shard_cap, [&](uint32_t i, bool valid, uint32_t) {
         if (valid) {
@@ -143,7 +144,7 @@ k_intersect_sched(PtTlasView tl, uint32_t* __restrict__ counters, uint32_t depth
 {
     __shared__ int s_stack[PT_LDS_STACK][kBlock];
     PtStack stk;
-    stk.lds = &s_stack[0][threadIdx.x];
+    stk.lds = (pt_lds_int*)&s_stack[0][threadIdx.x];
     stk.spill_base = spill;
     PtSchedQueue Q;
     Q.counters = counters; Q.shard_cap = shard_cap; Q.n_shards = kShards; Q.ctr_pad = kCtrPad;

@@ -163,8 +163,7 @@ __device__ __forceinline__ void pt_traverse_sched(const PtTlasView& tl, const Pt
                     if (pt_tri_test(cur, delta, a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, t, u, v)) {
                         const uint32_t prim = __float_as_uint(c.y);
                         if (t > tmin && t < tmax && t >= tlo && t <= thi) {
-                            const bool closer = (t < best.t) || (t == best.t && (cur_inst < best.inst || (cur_inst == best.inst && prim < best.prim)));
-                            if (closer) { best.t = t; best.inst = cur_inst; best.prim = prim; best.u = u; best.v = v; }
+                            pt_hit_update(best, t, cur_inst, prim, u, v);
                         }
                     }
                     // one triangle per step: first + 1, count - 1

@@ -1,0 +1,125 @@
+// pt_wide.h -- host-side construction of the traversal layout (plain C++, no device code).
+#pragma once
+#include "../../include/pt_hip.h"
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+#include <limits>
+#include <vector>
+
+// ---------------------------------------------------------------------------------------------
+// Traversal layout: 4-wide nodes with child boxes quantised to 8 bits on a per-node grid (64 bytes
+// for four children instead of 64 bytes for two).  The traversal kernels are bound by the number of
+// 16-byte-per-lane loads the texture path has to serve for scattered node fetches, so bytes per
+// child are what counts.  A wide node stands for a node of the canonical binary tree; its entries
+// are found by opening that node and then, while fewer than four entries exist, the inner entry
+// with the largest surface area.  Quantisation only ever grows a box
+// (checked with the same fma the kernels use to expand it), so the set of triangles a ray is tested
+// against can grow but the closest hit cannot change.
+struct PtWide4 {
+    float origin[3];
+    uint32_t exps;          // biased binary32 exponents of the grid step: x | y << 8 | z << 16
+    int32_t child[4];       // >= 0 wide node, < 0 leaf (~c = first << 3 | count - 1), INT32_MIN empty
+    uint32_t q[6];          // lo.x, lo.y, lo.z, hi.x, hi.y, hi.z; byte k of each word belongs to child k
+    uint32_t pad[2];
+};
+static_assert(sizeof(PtWide4) == 64, "wide node must be 64 bytes");
+
+static inline float pt_grid_plane(uint32_t q, uint32_t exp_byte, float origin)
+{
+    uint32_t bits = exp_byte << 23; float scale; memcpy(&scale, &bits, 4);
+    return __builtin_fmaf((float)q, scale, origin);
+}
+
+// Collapses one binary BVH (host copy) into wide nodes appended to `out`.  Inner references are
+// rebased by the position of the first appended node, leaf references by tri_base.  Returns the
+// depth of the wide tree (a single node has depth 1).
+static inline uint32_t pt_collapse_to_wide(const std::vector<PtBvhNode>& n2, uint32_t tri_base, std::vector<PtWide4>& out)
+{
+    const int32_t EMPTY = std::numeric_limits<int32_t>::min();
+    const uint32_t base = (uint32_t)out.size();
+    std::vector<uint32_t> todo { 0 };            // binary nodes that become wide nodes, in breadth-first order
+    std::vector<int32_t> wide_of(n2.size(), -1);
+    std::vector<uint32_t> depth_of { 1 };
+    uint32_t max_depth = 1;
+    wide_of[0] = 0;
+    for (size_t head = 0; head < todo.size(); ++head) {
+        const PtBvhNode& nd = n2[todo[head]];
+        struct Entry { int32_t ref; float lo[3], hi[3]; };
+        Entry ent[4]; int ne = 0;
+        auto add = [&](int32_t ref, const float* lo, const float* hi) { ent[ne].ref = ref; for (int k = 0; k < 3; ++k) { ent[ne].lo[k] = lo[k]; ent[ne].hi[k] = hi[k]; } ++ne; };
+        if (nd.c0 != EMPTY) add(nd.c0, nd.lo0, nd.hi0);
+        if (nd.c1 != EMPTY) add(nd.c1, nd.lo1, nd.hi1);
+        // open the inner entry with the largest surface area until the node is full
+#ifndef PT_WIDE_GREEDY
+#define PT_WIDE_GREEDY 1
+#endif
+        while (PT_WIDE_GREEDY ? ne < 4 : false) {
+            int pick = -1; float pick_area = -1.0f;
+            for (int e = 0; e < ne; ++e) {
+                if (ent[e].ref < 0) continue;
+                const float dx = ent[e].hi[0] - ent[e].lo[0], dy = ent[e].hi[1] - ent[e].lo[1], dz = ent[e].hi[2] - ent[e].lo[2];
+                const float area = dx * dy + dy * dz + dz * dx;
+                if (area > pick_area) { pick_area = area; pick = e; }
+            }
+            if (pick < 0) break;
+            const PtBvhNode& ch = n2[ent[pick].ref];
+            ent[pick] = ent[--ne];
+            if (ch.c0 != EMPTY) add(ch.c0, ch.lo0, ch.hi0);
+            if (ch.c1 != EMPTY) add(ch.c1, ch.lo1, ch.hi1);
+        }
+        PtWide4 w; memset(&w, 0, sizeof w);
+        float lo[3], hi[3];
+        for (int k = 0; k < 3; ++k) { lo[k] = ent[0].lo[k]; hi[k] = ent[0].hi[k]; }
+        for (int e = 1; e < ne; ++e) for (int k = 0; k < 3; ++k) { lo[k] = fminf(lo[k], ent[e].lo[k]); hi[k] = fmaxf(hi[k], ent[e].hi[k]); }
+        uint32_t ex[3];
+        for (int k = 0; k < 3; ++k) {
+            w.origin[k] = lo[k];
+            // smallest power-of-two step with 255 steps covering the extent; grown until every plane fits
+            int e2; float ext = hi[k] - lo[k];
+            if (!(ext > 0.0f)) e2 = -126; else { (void)frexpf(ext / 255.0f, &e2); }
+            int eb = e2 + 127; if (eb < 1) eb = 1; if (eb > 254) eb = 254;
+            for (;; ++eb) {
+                bool ok = true;
+                for (int e = 0; e < ne && ok; ++e) {
+                    uint32_t bits = (uint32_t)eb << 23; float scale; memcpy(&scale, &bits, 4);
+                    double qh = ceil(((double)ent[e].hi[k] - (double)lo[k]) / (double)scale);
+                    if (qh > 255.0) ok = false;
+                    else { uint32_t q = (uint32_t)(qh < 0 ? 0 : qh); while (q <= 255 && pt_grid_plane(q, (uint32_t)eb, lo[k]) < ent[e].hi[k]) ++q; if (q > 255) ok = false; }
+                }
+                if (ok || eb >= 254) break;
+            }
+            ex[k] = (uint32_t)eb;
+        }
+        w.exps = ex[0] | (ex[1] << 8) | (ex[2] << 16);
+        for (int e = 0; e < 4; ++e) w.child[e] = EMPTY;
+        for (int e = 0; e < ne; ++e) {
+            for (int k = 0; k < 3; ++k) {
+                uint32_t bits = ex[k] << 23; float scale; memcpy(&scale, &bits, 4);
+                double ql = floor(((double)ent[e].lo[k] - (double)lo[k]) / (double)scale);
+                uint32_t q_lo = (uint32_t)(ql < 0 ? 0 : (ql > 255 ? 255 : ql));
+                while (q_lo > 0 && pt_grid_plane(q_lo, ex[k], lo[k]) > ent[e].lo[k]) --q_lo;
+                double qh = ceil(((double)ent[e].hi[k] - (double)lo[k]) / (double)scale);
+                uint32_t q_hi = (uint32_t)(qh < 0 ? 0 : (qh > 255 ? 255 : qh));
+                while (q_hi < 255 && pt_grid_plane(q_hi, ex[k], lo[k]) < ent[e].hi[k]) ++q_hi;
+                w.q[k] |= q_lo << (8 * e);
+                w.q[3 + k] |= q_hi << (8 * e);
+            }
+            int32_t ref = ent[e].ref;
+            if (ref >= 0) {
+                if (wide_of[ref] < 0) {
+                    wide_of[ref] = (int32_t)todo.size(); todo.push_back((uint32_t)ref);
+                    depth_of.push_back(depth_of[head] + 1);
+                    max_depth = depth_of[head] + 1 > max_depth ? depth_of[head] + 1 : max_depth;
+                }
+                w.child[e] = (int32_t)(base + (uint32_t)wide_of[ref]);
+            } else {
+                uint32_t code = ~(uint32_t)ref;
+                w.child[e] = (int32_t)~((((code >> 3) + tri_base) << 3) | (code & 7u));
+            }
+        }
+        out.push_back(w);
+    }
+    return max_depth;
+}
+

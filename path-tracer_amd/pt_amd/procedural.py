@@ -217,3 +217,26 @@ def triangle_soup(n_tris, seed=1, extent=1.0, size=0.1, n_instances=1) -> Scene:
     model.meshes, model.nodes, model.materials = meshes, nodes, [mat]
     scene.add_model(model)
     return scene
+
+
+def stacked_copies(n_copies=6, n_tris=300, seed=5) -> Scene:
+    """The same mesh instanced n_copies times with the identity transform: every hit is an exact
+    tie in t between all copies, so the closest hit is decided by the (instance, primitive) order
+    alone, whatever order a traversal meets the copies in."""
+    rng = np.random.default_rng(seed)
+    scene = Scene()
+    mat = scene.tables.create_material(abi.default_material())
+    c = rng.uniform(-1.0, 1.0, size=(n_tris, 1, 3))
+    p = (c + rng.uniform(-0.3, 0.3, size=(n_tris, 3, 3))).reshape(-1, 3).astype(f32)
+    v = np.zeros((p.shape[0],), dtype=abi.VERTEX)
+    v["pos"] = p
+    n = rng.normal(size=p.shape)
+    v["normal"] = (n / np.linalg.norm(n, axis=1, keepdims=True)).astype(f32)
+    v["uv"] = rng.uniform(0, 1, size=(p.shape[0], 2)).astype(f32)
+    idx = np.arange(p.shape[0], dtype=np.uint32)
+    model = Model(vertices=v, indices=idx, name="stack")
+    model.meshes = [Mesh(index_count=int(idx.size), first_index=0, first_vertex=0, material=mat)]
+    model.nodes = [Node(f"copy{k}", None, np.eye(4, dtype=f32), [0]) for k in range(n_copies)]
+    model.materials = [mat]
+    scene.add_model(model)
+    return scene

@@ -35,3 +35,9 @@ def dragon():
 def soup():
     from pt_amd import procedural
     return procedural.triangle_soup(6000, seed=3, n_instances=4)
+
+
+@pytest.fixture(scope="session")
+def stacked():
+    from pt_amd import procedural
+    return procedural.stacked_copies()

@@ -104,6 +104,36 @@ def test_render_frame_bit_exact(name, w, h, spp, request):
         r.close()
 
 
+def test_exact_ties_between_instances(stacked, cornell):
+    """Ties in t are decided by (instance, primitive); every field of the winner must be reported.
+    (a) identical stacked copies: the traversal meets the copies in tree order, the answer is copy 0;
+    (b) a Cornell primary ray through the edge shared by the floor and the right wall, where both
+    triangles give the same t but different barycentrics."""
+    import oracle as O
+    r = _renderer(stacked, 64, 64)
+    try:
+        orc = O.OracleScene(stacked)
+        o, d = _random_rays(20000, 21, -2.0, 2.0)
+        hg, tg = r.intersect(o, d)
+        ho, to = orc.tlas.intersect(o, d)
+        assert np.array_equal(hg, ho) and _float_eq(tg, to)
+        hit = hg["instance"] != 0xFFFFFFFF
+        assert hit.mean() > 0.1 and np.all(hg["instance"][hit] == 0)
+    finally:
+        r.close()
+    r = _renderer(cornell, 64, 64)
+    try:
+        orc = O.OracleScene(cornell)
+        o = np.array([[0, 1, 3]], np.float32)
+        d = np.array([[1050287530, 3197771178, 3211240841]], np.uint32).view(np.float32)
+        hg, tg = r.intersect(o, d)
+        ho, to = orc.tlas.intersect(o, d)
+        assert (int(ho["instance"][0]), int(ho["primitive"][0])) == (0, 0)
+        assert np.array_equal(hg, ho) and _float_eq(tg, to)
+    finally:
+        r.close()
+
+
 def test_cfg1_golden_full_size(cornell):
     """BASELINE config 1 in full (Cornell 512x512, 16 spp, frame 0) against the committed oracle
     outputs: SHA-256 of the whole float image, the radiance crop, the ray count and the bounce-0 ids."""

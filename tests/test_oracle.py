@@ -169,6 +169,21 @@ def test_bvh_traversal_equals_brute_force(name, n, request):
     assert (hv["instance"] != 0xFFFFFFFF).mean() > 0.02
 
 
+def test_exact_ties_go_to_the_lowest_instance(stacked):
+    """Identical copies of one mesh: every hit ties in t across the copies; instance 0 must win
+    in the BVH traversal as in the brute-force loop."""
+    orc = O.OracleScene(stacked)
+    rng = np.random.default_rng(9)
+    o = rng.uniform(-2.0, 2.0, size=(4000, 3)).astype(np.float32)
+    d = rng.normal(size=(4000, 3))
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    hb, tb = orc.tlas.intersect(o, d, use_bvh=False)
+    hv, tv = orc.tlas.intersect(o, d, use_bvh=True)
+    assert np.array_equal(hb, hv) and np.array_equal(tb, tv)
+    hit = hv["instance"] != 0xFFFFFFFF
+    assert hit.mean() > 0.1 and np.all(hv["instance"][hit] == 0)
+
+
 def test_degenerate_directions_and_edges(cube):
     """Axis-aligned rays (zero direction components), rays through vertices and along edges."""
     orc = O.OracleScene(cube)

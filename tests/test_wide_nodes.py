@@ -1,0 +1,174 @@
+"""Host-side construction of the 4-wide quantised traversal nodes, checked without a GPU against
+the binary BVH the oracle builds (the GPU builder's binary nodes are bit-identical to it).
+
+A wide tree is valid when (1) it references every triangle position exactly once and every wide
+node exactly once, and (2) each entry's dequantised box contains the padded boxes of all triangles
+below it; with the monotone slab test (2) makes every ray reach every triangle it could hit, so
+the closest hit cannot depend on the layout."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle as O
+from pt_amd import abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "path-tracer_amd", "lib", "libpt_wide_host.so")
+
+WIDE4 = np.dtype([("origin", "<f4", 3), ("exps", "<u4"), ("child", "<i4", 4), ("q", "<u4", 6), ("pad", "<u4", 2)])
+EMPTY = -2**31
+
+
+@pytest.fixture(scope="module")
+def wide_lib():
+    if not os.path.exists(LIB):
+        pytest.fail("libpt_wide_host.so is not built (make -C path-tracer_amd/csrc)")
+    lib = C.CDLL(LIB)
+    lib.pt_wide_collapse_host.restype = C.c_uint32
+    lib.pt_wide_collapse_host.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+    lib.pt_wide_candidates_host.restype = C.c_uint32
+    lib.pt_wide_candidates_host.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_uint32]
+    return lib
+
+
+def collapse(lib, nodes, tri_base=0):
+    assert WIDE4.itemsize == 64
+    nodes = np.ascontiguousarray(nodes)
+    out = np.zeros(len(nodes) + 1, dtype=WIDE4)
+    depth = C.c_uint32(0)
+    n = lib.pt_wide_collapse_host(nodes.ctypes.data, len(nodes), tri_base, out.ctypes.data, len(out), C.byref(depth))
+    assert n > 0
+    return out[:n].copy(), depth.value
+
+
+def entry_box(w, e):
+    lo, hi = np.zeros(3, np.float32), np.zeros(3, np.float32)
+    for k in range(3):
+        scale = np.array([((int(w["exps"]) >> (8 * k)) & 255) << 23], np.uint32).view(np.float32)[0]
+        ql = (int(w["q"][k]) >> (8 * e)) & 255
+        qh = (int(w["q"][3 + k]) >> (8 * e)) & 255
+        # q * scale + origin is exact in binary64, so one rounding to binary32 equals the fma
+        lo[k] = np.float32(np.float64(ql) * np.float64(scale) + np.float64(w["origin"][k]))
+        hi[k] = np.float32(np.float64(qh) * np.float64(scale) + np.float64(w["origin"][k]))
+    return lo, hi
+
+
+def padded_prim_boxes(blas):
+    """Boxes of the triangles in leaf order, padded by the BLAS's delta, in binary32."""
+    v = blas.vertices["pos"] if "pos" in blas.vertices.dtype.names else None
+    assert v is not None
+    idx = blas.indices[:3 * blas.prim_count].reshape(-1, 3)[blas.leaf_prims()]
+    p = v[idx]                                   # [n, 3 corners, 3]
+    d = np.float32(blas.delta())
+    return (p.min(axis=1) - d).astype(np.float32), (p.max(axis=1) + d).astype(np.float32)
+
+
+def check_wide(wide, depth, prim_lo, prim_hi, n_prims, tri_base=0):
+    seen = np.zeros(n_prims, np.int32)
+    node_seen = np.zeros(len(wide), np.int32)
+    node_seen[0] = 1
+    max_depth = 0
+
+    def visit(i, d):
+        nonlocal max_depth
+        max_depth = max(max_depth, d)
+        w = wide[i]
+        lo_all = np.full(3, np.inf, np.float32)
+        hi_all = np.full(3, -np.inf, np.float32)
+        n_entries = 0
+        for e in range(4):
+            c = int(w["child"][e])
+            if c == EMPTY:
+                continue
+            n_entries += 1
+            if c >= 0:
+                node_seen[c] += 1
+                lo, hi = visit(c, d + 1)
+            else:
+                code = (~c) & 0xFFFFFFFF
+                first, cnt = (code >> 3) - tri_base, (code & 7) + 1
+                seen[first:first + cnt] += 1
+                lo, hi = prim_lo[first:first + cnt].min(axis=0), prim_hi[first:first + cnt].max(axis=0)
+            qlo, qhi = entry_box(w, e)
+            assert np.all(qlo <= lo) and np.all(qhi >= hi), (i, e, qlo, lo, qhi, hi)
+            lo_all, hi_all = np.minimum(lo_all, lo), np.maximum(hi_all, hi)
+        assert n_entries >= 1
+        return lo_all, hi_all
+
+    visit(0, 1)
+    assert np.all(seen == 1) and np.all(node_seen == 1)
+    assert max_depth == depth
+
+
+@pytest.mark.parametrize("name", ["cornell", "cube", "soup", "dragon"])
+def test_wide_tree_is_a_conservative_partition(name, request, wide_lib):
+    scene = request.getfixturevalue(name)
+    orc = O.OracleScene(scene)
+    done = set()
+    for b in orc.blases:
+        key = (b.vertices.ctypes.data, b.indices.ctypes.data, b.prim_count)
+        if key in done:
+            continue
+        done.add(key)
+        wide, depth = collapse(wide_lib, b.nodes())
+        lo, hi = padded_prim_boxes(b)
+        check_wide(wide, depth, lo, hi, b.prim_count)
+        # fuller nodes than a binary tree: fewer wide nodes than binary nodes unless the tree is tiny
+        assert len(wide) <= max(1, len(b.nodes()))
+    # TLAS: leaves are instances, boxes are the instance world boxes
+    leaf_inst = orc.tlas.leaf_instances()
+    boxes = [orc.tlas.instance_box(int(i)) for i in leaf_inst]
+    lo = np.stack([b[0] for b in boxes]); hi = np.stack([b[1] for b in boxes])
+    wide, depth = collapse(wide_lib, orc.tlas.nodes())
+    check_wide(wide, depth, lo, hi, orc.tlas.n)
+
+
+def test_leaf_references_are_rebased(cube, wide_lib):
+    orc = O.OracleScene(cube)
+    b = orc.blases[0]
+    w0, _ = collapse(wide_lib, b.nodes(), 0)
+    w1, _ = collapse(wide_lib, b.nodes(), 1000)
+    for a, c in zip(w0["child"].ravel(), w1["child"].ravel()):
+        if a < 0 and a != EMPTY:
+            ca, cc = (~int(a)) & 0xFFFFFFFF, (~int(c)) & 0xFFFFFFFF
+            assert (cc >> 3) == (ca >> 3) + 1000 and (cc & 7) == (ca & 7)
+        else:
+            assert a == c
+
+
+@pytest.mark.parametrize("name,n", [("cube", 3000), ("soup", 1500), ("dragon", 300)])
+def test_rays_reach_the_triangle_they_hit(name, n, request, wide_lib):
+    """Object-space rays against single BLASes placed with the identity transform."""
+    from pt_amd import abi as A
+    scene = request.getfixturevalue(name)
+    orc = O.OracleScene(scene)
+    b = max(orc.blases, key=lambda x: x.prim_count)
+    ident = np.eye(4, dtype=np.float32)[:3, :]
+    tl = O.Tlas(np.stack([A.make_instance(ident, 0, b.h)]).astype(A.INSTANCE), [b])
+    rlo, rhi = b.root_box()
+    rng = np.random.default_rng(11)
+    c, ext = (rlo + rhi) / 2, float(np.max(rhi - rlo))
+    o = (c + rng.uniform(-1.0, 1.0, size=(n, 3)) * ext).astype(np.float32)
+    tgt = (c + rng.uniform(-0.5, 0.5, size=(n, 3)) * (rhi - rlo)).astype(np.float32)
+    d = tgt - o
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    hits, t = tl.intersect(o, d)
+    wide, _ = collapse(wide_lib, b.nodes())
+    leaf_prims = b.leaf_prims()
+    codes = np.zeros(b.prim_count + 8, np.uint32)
+    n_hit = 0
+    for i in range(n):
+        if hits["instance"][i] == 0xFFFFFFFF:
+            continue
+        n_hit += 1
+        oi, di = np.ascontiguousarray(o[i]), np.ascontiguousarray(d[i])
+        m = wide_lib.pt_wide_candidates_host(wide.ctypes.data, 0, oi.ctypes.data, di.ctypes.data, 0.001, 10000.0, codes.ctypes.data, len(codes))
+        assert m <= len(codes)
+        reach = set()
+        for code in codes[:m]:
+            first, cnt = int(code) >> 3, (int(code) & 7) + 1
+            reach.update(leaf_prims[first:first + cnt].tolist())
+        assert int(hits["primitive"][i]) in reach
+    assert n_hit > n // 20
