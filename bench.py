@@ -3,9 +3,10 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-One step = one frame (pt_trace) of --spp samples per pixel over the whole 1920x1080 image of the
+One step = one pt_trace call of --spp samples per pixel over the whole 1920x1080 image of the
 dragon scene (procedural stand-in for the missing DragonAttenuation.bin), all inputs resident in
-HBM.  With N > 1 (one process per GPU under torch.distributed.run) rank r renders frames
+HBM; up to --frames-in-flight steps overlap on the library's internal streams.  With N > 1 (one
+process per GPU under torch.distributed.run) rank r renders frames
 r, r+N, r+2N, ... (samples-per-pixel sharding) into its own float sum buffer and the buffers are
 summed with one RCCL all-reduce inside the timed region; per-GPU work is fixed, so scaling is weak.
 Rank 0 prints one JSON line.
@@ -69,8 +70,9 @@ def main():
     ap.add_argument("--scene", default="dragon", choices=["dragon", "cornell", "cube"])
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--spp", type=int, default=16, help="samples per pixel per step (frame)")
+    ap.add_argument("--spp", type=int, default=64, help="samples per pixel per step (one pt_trace call)")
     ap.add_argument("--max-depth", type=int, default=10)
+    ap.add_argument("--frames-in-flight", type=int, default=3, help="steps the library keeps in flight on separate streams")
     ap.add_argument("--cpu-spp", type=int, default=16, help="samples per pixel of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the cornell side measurement")
@@ -98,6 +100,7 @@ def main():
     setup_s = time.perf_counter() - t0
     build_ms = sum(float(b.info()["build_ms"]) for b in r.blases) + float(r.tlas.info()["build_ms"])
     accum = torch.zeros(H * W * 4, dtype=torch.float32, device="cuda")
+    r.ctx.set_frames_in_flight(args.frames_in_flight)
 
     def barrier():
         torch.cuda.synchronize()
@@ -107,14 +110,20 @@ def main():
 
     # warmup (frames that are not part of the timed set)
     run_steps(r, accum.data_ptr(), args.warmup, 1_000_000, rank, world, args.spp, args.max_depth)
+    r.ctx.sync()                    # frames in flight still add to the image
     accum.zero_()
     r.reset_stats()
+    # the dominant kernel (intersect) is bracketed by HIP events on the streams it runs on, during the timed steps
+    r.set_profiling(True)
+    r.profile()
     barrier()
     t0 = time.perf_counter()
     run_steps(r, accum.data_ptr(), args.steps, 0, rank, world, args.spp, args.max_depth)
+    r.ctx.sync()                    # the all-reduce (torch's stream) follows every frame in flight
     sharding.allreduce_sum(accum)
     barrier()
     elapsed = time.perf_counter() - t0
+    prof = r.profile()
     st = r.stats()
     rays_local, paths_local = int(st["rays"]), int(st["paths"])
     t = torch.tensor([elapsed, float(rays_local), float(paths_local)], dtype=torch.float64, device="cuda")
@@ -128,12 +137,14 @@ def main():
         rays, paths = float(rays_local), float(paths_local)
     # sanity: the reduced buffer holds every frame of every rank
     frames_seen = float(accum.view(-1, 4)[0, 3])
-
-    # --- dominant kernel (intersect) timed with HIP events on the stream it runs on
-    r.set_profiling(True)
-    r.profile()
-    run_steps(r, accum.data_ptr(), min(args.steps, 4), 2_000_000, rank, world, args.spp, args.max_depth)
-    prof = r.profile()
+    # the same kernel with one frame at a time, so that a launch has the GPU to itself (not part of `value`)
+    prof_serial = None
+    if rank == 0 and args.frames_in_flight > 1:
+        r.ctx.set_frames_in_flight(1)
+        run_steps(r, accum.data_ptr(), 1, 3_000_000, 0, 1, args.spp, args.max_depth)
+        r.profile()
+        run_steps(r, accum.data_ptr(), 2, 3_000_001, 0, 1, args.spp, args.max_depth)
+        prof_serial = r.profile()
     r.set_profiling(False)
 
     if rank == 0:
@@ -169,11 +180,19 @@ def main():
             "bound": "hbm", "kernel": "k_intersect", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": None,
             "launches": i_n, "avg_launch_ms": i_ms / max(i_n, 1), "rays_per_launch": i_rays / max(i_n, 1),
+            "frames_in_flight": args.frames_in_flight,
             "bytes_per_ray": bytes_intersect, "box_tests_per_ray": vn, "tri_tests_per_ray": vt,
             "intersect_rays_per_s": i_rays / (i_ms * 1e-3) if i_ms > 0 else 0.0,
             "pipeline_bytes_per_ray": bytes_pipeline,
             "pipeline_frac": (rays / elapsed / world) * bytes_pipeline / 1e9 / HBM_PEAK_GBS,
         }
+        if prof_serial is not None and float(prof_serial["intersect_ms"]) > 0:
+            s_ms, s_rays, s_n = float(prof_serial["intersect_ms"]), float(prof_serial["intersect_rays"]), int(prof_serial["intersect_launches"])
+            s_ach = (s_rays * bytes_intersect) / (s_ms * 1e-3) / 1e9
+            # launches of frames in flight share the GPU, which stretches each of them; this is the
+            # same measurement with frames strictly one after the other
+            out["roofline"]["one_frame_at_a_time"] = {"achieved": s_ach, "frac": s_ach / HBM_PEAK_GBS, "launches": s_n,
+                                                      "avg_launch_ms": s_ms / max(s_n, 1), "intersect_rays_per_s": s_rays / (s_ms * 1e-3)}
         if world == 1 and not args.no_secondary and args.scene == "dragon":
             r.close()
             c = hip.Renderer(build_scene("cornell"), W, H, device=local_rank, stream=stream)

@@ -105,7 +105,24 @@ const char* pt_last_error(void);
  * hipStream_t to enqueue on (for example PyTorch's current stream). */
 int pt_ctx_create(int device_id, void* hip_stream, PtContext** out);
 int pt_ctx_destroy(PtContext* ctx);
+/* Waits on the host for everything the context has enqueued, frames in flight included. */
 int pt_sync(PtContext* ctx);
+
+/* Replaces the per-frame command buffers and fences the reference cycles through
+ * (source/renderer.cpp:52-62, MAX_FRAMES_IN_FLIGHT = 3 in include/vk_common.hpp:6): pt_trace puts
+ * every frame (every pixel chunk of it) on the next of n internal streams, each with its own path
+ * queues, and returns without waiting, so the thin late bounces of one frame overlap the wide early
+ * bounces of the next.  Work the caller enqueued on its own stream before a pt_trace call is
+ * waited for by that frame; updates of the accumulation image happen in submission order.
+ * Default 3 (environment: PT_HIP_FRAMES_IN_FLIGHT); 1 restores strictly serial frames.
+ * Changing the number waits for all frames and releases their queues. */
+int pt_ctx_set_frames_in_flight(PtContext* ctx, int n);
+/* Vulkan's vkWaitForFences(_inFlightFences) of source/renderer.cpp:64-65 as a stream operation:
+ * makes the context's stream wait for all frames in flight without blocking the host.  Call it
+ * before enqueuing your own work that reads the accumulation image on that stream; every entry
+ * point of this library that reads results (pt_accum_resolve, pt_trace_last_result,
+ * pt_trace_stats, pt_trace_profile, pt_buffer_download, pt_intersect's outputs) does so itself. */
+int pt_trace_fence(PtContext* ctx);
 
 /* Replaces the staging-buffer uploads of source/model_loader.cpp:307-357 and
  * source/resources/gpu_resources.cpp:207-271: hipMalloc + copy.  Synchronous. */
@@ -165,10 +182,11 @@ int pt_trace(PtContext* ctx, const PtTlas* tlas, const float camera[32], uint32_
 int pt_trace_last_result(PtContext* ctx, float* result_host);
 int pt_trace_stats(PtContext* ctx, PtTraceStats* out);       /* synchronous */
 int pt_trace_stats_reset(PtContext* ctx);
-/* Timing of the intersect kernel with HIP events on the context's stream (off by default).
- * While enabled, every intersect launch of pt_trace is bracketed by an event pair;
- * pt_trace_profile waits for the stream, adds up the pairs recorded since the last call and
- * returns them.  Has no counterpart in the reference (it has no timers). */
+/* Timing of the intersect kernel with HIP events on the streams it is launched on (off by
+ * default).  While enabled, every intersect launch of pt_trace is bracketed by an event pair;
+ * pt_trace_profile waits for all frames, adds up the pairs recorded since the last call and
+ * returns them.  With several frames in flight the launches of different frames overlap, so the
+ * sum is kernel time, not elapsed time.  Has no counterpart in the reference (it has no timers). */
 typedef struct PtTraceProfile {
     uint64_t intersect_launches;
     uint64_t intersect_rays;
@@ -177,7 +195,9 @@ typedef struct PtTraceProfile {
 int pt_ctx_set_profiling(PtContext* ctx, int enabled);
 int pt_trace_profile(PtContext* ctx, PtTraceProfile* out);
 
-/* Upper bound on paths resident at once (default 1<<25); a frame is rendered in pixel chunks. */
+/* Upper bound on paths resident at once per frame in flight (default 1<<27, about 21 GB of queues
+ * when reached; queues are sized by the largest chunk actually traced); a larger frame is
+ * rendered in pixel chunks. */
 int pt_ctx_set_max_paths(PtContext* ctx, uint64_t max_paths);
 
 /* Replaces the render-target -> swapchain blit (source/renderer.cpp:124-133): float sum buffer

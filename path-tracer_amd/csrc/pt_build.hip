@@ -714,6 +714,7 @@ int pt_tlas_build(PtContext* ctx, const PtInstance* instances, uint32_t n, PtTla
 int pt_tlas_destroy(PtTlas* t)
 {
     if (!t) return PT_OK;
+    (void)pt_lanes_sync(t->ctx);   // frames in flight traverse the pool
     (void)hipFree(t->nodes); (void)hipFree(t->leaf_inst); (void)hipFree(t->inst); (void)hipFree(t->shade_inst);
     (void)hipFree(t->pool_nodes); (void)hipFree(t->pool_tris);
     delete t;

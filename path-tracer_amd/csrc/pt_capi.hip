@@ -24,6 +24,64 @@ static int replace_table(T** dst, uint32_t* n_dst, const T* src, uint32_t n)
     return PT_OK;
 }
 
+static void lane_free(PtLane& l)
+{
+    for (int a = 0; a < 2; ++a) for (int k = 0; k < 4; ++k) (void)hipFree(l.q[a][k]);
+    (void)hipFree(l.hits); (void)hipFree(l.path_result); (void)hipFree(l.counters); (void)hipFree(l.spill);
+    if (l.done) (void)hipEventDestroy(l.done);
+    if (l.accumulated) (void)hipEventDestroy(l.accumulated);
+    if (l.stream) (void)hipStreamDestroy(l.stream);
+    l = PtLane();
+}
+
+int pt_lanes_sync(PtContext* c)
+{
+    PT_HIP_CHECK(hipSetDevice(c->device));
+    for (PtLane& l : c->lanes) if (l.stream) PT_HIP_CHECK(hipStreamSynchronize(l.stream));
+    for (PtLane& l : c->lanes) l.pending = false;
+    c->last_accumulate = nullptr;
+    PT_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return PT_OK;
+}
+
+int pt_lanes_join(PtContext* c)
+{
+    for (PtLane& l : c->lanes) {
+        if (!l.pending) continue;
+        PT_HIP_CHECK(hipEventRecord(l.done, l.stream));
+        PT_HIP_CHECK(hipStreamWaitEvent(c->stream, l.done, 0));
+        l.pending = false;
+    }
+    return PT_OK;
+}
+
+int pt_lanes_resize(PtContext* c, int n)
+{
+    int rc = pt_lanes_sync(c);
+    if (rc) return rc;
+    for (PtLane& l : c->lanes) lane_free(l);
+    c->lanes.assign((size_t)n, PtLane());
+    c->next_lane = 0; c->last_accumulate = nullptr;
+    for (PtLane& l : c->lanes) {
+        PT_HIP_CHECK(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
+        PT_HIP_CHECK(hipEventCreateWithFlags(&l.done, hipEventDisableTiming));
+        PT_HIP_CHECK(hipEventCreateWithFlags(&l.accumulated, hipEventDisableTiming));
+    }
+    return PT_OK;
+}
+
+int pt_lane_begin(PtContext* c, PtLane** out)
+{
+    PtLane& l = c->lanes[c->next_lane % c->lanes.size()];
+    c->next_lane++;
+    // whatever the caller enqueued on its stream so far (uploads, a resolve that reads the image) comes first
+    PT_HIP_CHECK(hipEventRecord(c->start_ev, c->stream));
+    PT_HIP_CHECK(hipStreamWaitEvent(l.stream, c->start_ev, 0));
+    l.pending = true;
+    *out = &l;
+    return PT_OK;
+}
+
 extern "C" {
 
 const char* pt_last_error(void) { return g_error; }
@@ -47,19 +105,34 @@ int pt_ctx_create(int device_id, void* hip_stream, PtContext** out)
         if (e != hipSuccess) { delete c; pt_set_error("hipStreamCreate failed: %s", hipGetErrorString(e)); return PT_ERROR_HIP; }
         c->own_stream = true;
     }
+    int lanes = 3;
+    if (const char* e = getenv("PT_HIP_FRAMES_IN_FLIGHT")) { lanes = atoi(e); if (lanes < 1) lanes = 1; if (lanes > 8) lanes = 8; }
+    hipError_t ee = hipEventCreateWithFlags(&c->start_ev, hipEventDisableTiming);
+    if (ee != hipSuccess || pt_lanes_resize(c, lanes) != PT_OK) {
+        if (ee != hipSuccess) pt_set_error("hipEventCreate failed: %s", hipGetErrorString(ee));
+        pt_ctx_destroy(c);
+        return PT_ERROR_HIP;
+    }
     *out = c;
     return PT_OK;
+}
+
+int pt_ctx_set_frames_in_flight(PtContext* c, int n)
+{
+    PT_REQUIRE(c, "null argument");
+    PT_REQUIRE(n >= 1 && n <= 8, "frames in flight must be in [1, 8]");
+    return pt_lanes_resize(c, n);
 }
 
 int pt_ctx_destroy(PtContext* c)
 {
     if (!c) return PT_OK;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    (void)pt_lanes_sync(c);
+    for (PtLane& l : c->lanes) lane_free(l);
+    if (c->start_ev) (void)hipEventDestroy(c->start_ev);
     PtWorkspace& w = c->ws;
-    for (int a = 0; a < 2; ++a) for (int k = 0; k < 4; ++k) (void)hipFree(w.q[a][k]);
-    (void)hipFree(w.hits); (void)hipFree(w.path_result); (void)hipFree(w.frame_result);
-    (void)hipFree(w.counters); (void)hipFree(w.stats); (void)hipFree(w.cam); (void)hipFree(w.spill);
+    (void)hipFree(w.frame_result); (void)hipFree(w.stats);
     (void)hipFree(c->materials); (void)hipFree(c->geometry_nodes); (void)hipFree(c->blas_instances); (void)hipFree(c->textures);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -70,9 +143,14 @@ int pt_ctx_destroy(PtContext* c)
 int pt_sync(PtContext* c)
 {
     PT_REQUIRE(c, "null argument");
+    return pt_lanes_sync(c);
+}
+
+int pt_trace_fence(PtContext* c)
+{
+    PT_REQUIRE(c, "null argument");
     PT_HIP_CHECK(hipSetDevice(c->device));
-    PT_HIP_CHECK(hipStreamSynchronize(c->stream));
-    return PT_OK;
+    return pt_lanes_join(c);
 }
 
 int pt_ctx_set_max_paths(PtContext* c, uint64_t max_paths)
@@ -100,8 +178,8 @@ int pt_buffer_upload(PtContext* c, const void* host, size_t bytes, void** dev_ou
 int pt_buffer_download(PtContext* c, const void* dev, size_t bytes, void* host_out)
 {
     PT_REQUIRE(c && dev && host_out, "null argument");
-    PT_HIP_CHECK(hipSetDevice(c->device));
-    PT_HIP_CHECK(hipStreamSynchronize(c->stream));
+    int rc = pt_lanes_sync(c);
+    if (rc) return rc;
     PT_HIP_CHECK(hipMemcpy(host_out, dev, bytes, hipMemcpyDeviceToHost));
     return PT_OK;
 }
@@ -109,7 +187,8 @@ int pt_buffer_download(PtContext* c, const void* dev, size_t bytes, void* host_o
 int pt_buffer_free(PtContext* c, void* dev)
 {
     PT_REQUIRE(c, "null argument");
-    PT_HIP_CHECK(hipSetDevice(c->device));
+    int rc = pt_lanes_sync(c);   // a frame in flight may still read or write the buffer
+    if (rc) return rc;
     PT_HIP_CHECK(hipFree(dev));
     return PT_OK;
 }
@@ -138,9 +217,8 @@ int pt_scene_set_tables(PtContext* c,
         if (materials[i].useAlbedoMap) PT_REQUIRE(materials[i].albedoMapIndex < n_textures, "Material.albedoMapIndex out of range");
     for (uint32_t i = 0; i < n_textures; ++i)
         PT_REQUIRE(textures[i].rgba8_dev && textures[i].width && textures[i].height, "empty texture");
-    PT_HIP_CHECK(hipSetDevice(c->device));
-    PT_HIP_CHECK(hipStreamSynchronize(c->stream));
-    int rc;
+    int rc = pt_lanes_sync(c);
+    if (rc) return rc;
     if ((rc = replace_table(&c->materials, &c->n_materials, materials, n_materials))) return rc;
     if ((rc = replace_table(&c->geometry_nodes, &c->n_geometry_nodes, geometry_nodes, n_geometry_nodes))) return rc;
     if ((rc = replace_table(&c->blas_instances, &c->n_blas_instances, blas_instances, n_blas_instances))) return rc;

@@ -189,14 +189,23 @@ __device__ __forceinline__ int pt_wide_step(const PtRaySpace& r, const float4* _
     const uint32_t Hx = __float_as_uint(h2.w), Hy = __float_as_uint(h3.x), Hz = __float_as_uint(h3.y);
     const int ref_in[4] = { __float_as_int(h1.x), __float_as_int(h1.y), __float_as_int(h1.z), __float_as_int(h1.w) };
     const float inf = __builtin_inff();
+    // The plane distance fma(x, 1/d, -o/d) is monotone in x, so the nearer plane of an axis is the
+    // low one when 1/d > 0 and the high one otherwise: picking the plane words by the sign gives
+    // the same interval as taking min and max of both distances.
+    const bool nx = r.ix < 0.0f, ny = r.iy < 0.0f, nz = r.iz < 0.0f;
+    const uint32_t Nx = nx ? Hx : Lx, Fx = nx ? Lx : Hx;
+    const uint32_t Ny = ny ? Hy : Ly, Fy = ny ? Ly : Hy;
+    const uint32_t Nz = nz ? Hz : Lz, Fz = nz ? Lz : Hz;
     float tn[4]; int ref[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const float lox = PT_FMA((float)((Lx >> (8 * k)) & 255u), sx, h0.x), hix = PT_FMA((float)((Hx >> (8 * k)) & 255u), sx, h0.x);
-        const float loy = PT_FMA((float)((Ly >> (8 * k)) & 255u), sy, h0.y), hiy = PT_FMA((float)((Hy >> (8 * k)) & 255u), sy, h0.y);
-        const float loz = PT_FMA((float)((Lz >> (8 * k)) & 255u), sz, h0.z), hiz = PT_FMA((float)((Hz >> (8 * k)) & 255u), sz, h0.z);
-        float a, b;
-        pt_slab(r, lox, loy, loz, hix, hiy, hiz, a, b);
+        const float ax = PT_FMA(PT_FMA((float)((Nx >> (8 * k)) & 255u), sx, h0.x), r.ix, -r.oox);
+        const float ay = PT_FMA(PT_FMA((float)((Ny >> (8 * k)) & 255u), sy, h0.y), r.iy, -r.ooy);
+        const float az = PT_FMA(PT_FMA((float)((Nz >> (8 * k)) & 255u), sz, h0.z), r.iz, -r.ooz);
+        const float bx = PT_FMA(PT_FMA((float)((Fx >> (8 * k)) & 255u), sx, h0.x), r.ix, -r.oox);
+        const float by = PT_FMA(PT_FMA((float)((Fy >> (8 * k)) & 255u), sy, h0.y), r.iy, -r.ooy);
+        const float bz = PT_FMA(PT_FMA((float)((Fz >> (8 * k)) & 255u), sz, h0.z), r.iz, -r.ooz);
+        const float a = fmaxf(fmaxf(ax, ay), az), b = fminf(fminf(bx, by), bz);
         const bool hit = (ref_in[k] != PT_NODE_EMPTY) && fmaxf(a, tlo) <= fminf(b, hi);
         tn[k] = hit ? a : inf;
         ref[k] = ref_in[k];

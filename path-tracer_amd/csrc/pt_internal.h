@@ -78,18 +78,27 @@ struct PtTlas {
     float build_ms;
 };
 
-struct PtWorkspace {
+// One frame in flight: its own stream and path queues, so that the thin late bounces of one frame
+// overlap the wide early bounces of the next.  The reference cycles its per-frame command buffers
+// and fences the same way (source/renderer.cpp:62, MAX_FRAMES_IN_FLIGHT in include/vk_common.hpp:6).
+struct PtLane {
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;         // recorded after the latest kernel enqueued on this lane
+    hipEvent_t accumulated = nullptr;  // recorded after the latest k_accumulate on this lane
+    bool pending = false;              // work enqueued since the last join
     uint64_t paths_cap = 0;            // slots per stream = kShards * shard_cap
     uint32_t shard_cap = 0;            // slots per shard (multiple of 64)
     float4* q[2][4] = { { nullptr, nullptr, nullptr, nullptr }, { nullptr, nullptr, nullptr, nullptr } };
     PtHit* hits = nullptr;
     float4* path_result = nullptr;     // per path: final hitValue (xyz)
+    uint32_t* counters = nullptr;      // queue sizes per depth (+ work counters)
+    int* spill = nullptr;              // traversal stack overflow, PT_SPILL_STACK ints per persistent thread
+};
+
+struct PtWorkspace {                   // shared by all lanes
     float* frame_result = nullptr;     // per pixel x 3
     uint64_t frame_pixels_cap = 0;
-    uint32_t* counters = nullptr;      // queue sizes per depth (+ work counters)
     uint64_t* stats = nullptr;         // PT_MAX_DEPTH rays-per-depth + paths
-    float* cam = nullptr;              // 32 floats
-    int* spill = nullptr;              // traversal stack overflow, PT_SPILL_STACK ints per persistent thread
     uint64_t spill_threads = 0;
 };
 
@@ -102,7 +111,7 @@ struct PtContext {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int num_cus = 0;
-    uint64_t max_paths = 1ull << 25;
+    uint64_t max_paths = 1ull << 27;
     int traversal_mode = 1;   // 0: one batch of 64 rays per wave at a time; 1: wave-scheduled with ray replacement (PT_HIP_TRAVERSAL=plain|sched)
     // tables
     PtMaterial* materials = nullptr; uint32_t n_materials = 0;
@@ -113,6 +122,10 @@ struct PtContext {
     std::vector<PtBLASInstance> h_blas_instances; std::vector<PtTextureDesc> h_textures;
     uint64_t tables_version = 0;
     PtWorkspace ws;
+    std::vector<PtLane> lanes;                 // frames in flight (PT_HIP_FRAMES_IN_FLIGHT, pt_ctx_set_frames_in_flight)
+    uint32_t next_lane = 0;
+    PtLane* last_accumulate = nullptr;         // lane whose k_accumulate every later one has to follow
+    hipEvent_t start_ev = nullptr;             // marks the caller's stream at the start of a unit of work
     uint32_t last_w = 0, last_h = 0;
     // intersect-kernel timing (pt_ctx_set_profiling)
     bool profiling = false;
@@ -121,6 +134,12 @@ struct PtContext {
     std::vector<uint32_t> ev_depth;            // depth of each recorded pair
     uint64_t stats_mark[PT_MAX_DEPTH] = {};    // rays_per_depth at the last pt_trace_profile
 };
+
+// pt_capi.hip: frames in flight
+int pt_lanes_resize(PtContext* ctx, int n);                 // waits for everything, then recreates the lanes
+int pt_lane_begin(PtContext* ctx, PtLane** out);            // next lane, ordered after the caller's stream
+int pt_lanes_join(PtContext* ctx);                          // the caller's stream waits for every lane (no host wait)
+int pt_lanes_sync(PtContext* ctx);                          // the host waits for every lane and the caller's stream
 
 // pt_build.hip
 int pt_build_lbvh(PtContext* ctx, const float* prim_boxes_dev /* n x 6: lo, hi */, uint32_t n, uint32_t max_leaf,

@@ -80,9 +80,11 @@ __device__ __forceinline__ void for_each_batch(uint32_t* __restrict__ counters, 
 }
 
 // ------------------------------------------------------------------------------------------------
+struct PtCameraArg { float m[32]; };
+
 __global__ void __launch_bounds__(kBlock)
 k_generate(uint32_t n_paths, uint32_t pixel0, uint32_t spp, uint32_t W, uint32_t H, uint32_t frame, uint32_t seed_mode,
-           uint32_t shard_cap, const float* __restrict__ cam /* 32 floats, device */, float4* __restrict__ q0,
+           uint32_t shard_cap, PtCameraArg camera /* viewInverse, projInverse; by value: no copy to wait for */, float4* __restrict__ q0,
            float4* __restrict__ q1, float4* __restrict__ q2, float4* __restrict__ q3, uint32_t* __restrict__ counters)
 {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
@@ -90,7 +92,7 @@ k_generate(uint32_t n_paths, uint32_t pixel0, uint32_t spp, uint32_t W, uint32_t
     if (q >= n_paths) return;
     const uint32_t pixel = pixel0 + q / spp, s = q % spp;
     const uint32_t px = pixel % W, py = pixel / W;
-    const float* VI = cam; const float* PI = cam + 16;
+    const float* VI = camera.m; const float* PI = camera.m + 16;
     float uvx = ((float)px + 0.5f) / (float)W;
     float uvy = ((float)py + 0.5f) / (float)H;
     float dx = uvx * 2.0f - 1.0f, dy = uvy * 2.0f - 1.0f;
@@ -364,8 +366,9 @@ __global__ void k_stats(const uint32_t* __restrict__ counters, uint32_t max_dept
     const uint32_t d = blockIdx.x, s = threadIdx.x;   // one wave per depth, one lane per shard
     uint32_t c = (d < max_depth && s < kShards) ? counters[ctr_index(CTR_COUNT, d, s)] : 0u;
     for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
-    if (s == 0 && d < max_depth) stats[d] += c;
-    if (s == 0 && d == 0) stats[PT_MAX_DEPTH] += n_paths;
+    // lanes run this concurrently
+    if (s == 0 && d < max_depth) atomicAdd((unsigned long long*)&stats[d], (unsigned long long)c);
+    if (s == 0 && d == 0) atomicAdd((unsigned long long*)&stats[PT_MAX_DEPTH], (unsigned long long)n_paths);
 }
 
 __global__ void k_resolve(uint32_t n, const float4* __restrict__ sum, uchar4* __restrict__ out, int bgra)
@@ -391,31 +394,35 @@ int persistent_blocks(PtContext* ctx, const void* kernel)
     return ctx->num_cus * per_cu;
 }
 
-int ensure_workspace(PtContext* ctx, uint64_t paths, uint64_t pixels)
+int ensure_workspace(PtContext* ctx, PtLane& l, uint64_t paths, uint64_t pixels)
 {
     PtWorkspace& w = ctx->ws;
-    if (!w.counters) {
-        PT_HIP_CHECK(hipMalloc((void**)&w.counters, sizeof(uint32_t) * kCounterWords));
+    if (!w.stats) {
         PT_HIP_CHECK(hipMalloc((void**)&w.stats, sizeof(uint64_t) * (PT_MAX_DEPTH + 1)));
         PT_HIP_CHECK(hipMemset(w.stats, 0, sizeof(uint64_t) * (PT_MAX_DEPTH + 1)));
-        PT_HIP_CHECK(hipMalloc((void**)&w.cam, sizeof(float) * 32));
         w.spill_threads = (uint64_t)ctx->num_cus * 8 * kBlock;
-        PT_HIP_CHECK(hipMalloc((void**)&w.spill, sizeof(int) * PT_SPILL_STACK * w.spill_threads));
+    }
+    if (!l.counters) {
+        PT_HIP_CHECK(hipMalloc((void**)&l.counters, sizeof(uint32_t) * kCounterWords));
+        PT_HIP_CHECK(hipMalloc((void**)&l.spill, sizeof(int) * PT_SPILL_STACK * w.spill_threads));
     }
     // per-shard capacity: the batches dealt to one shard, in slots
     const uint64_t batches = (paths + 63) / 64;
     const uint64_t cap = ((batches + kShards - 1) / kShards) * 64;
-    if (cap > w.shard_cap) {
-        for (int a = 0; a < 2; ++a) for (int k = 0; k < 4; ++k) { (void)hipFree(w.q[a][k]); w.q[a][k] = nullptr; }
-        (void)hipFree(w.hits); (void)hipFree(w.path_result); w.hits = nullptr; w.path_result = nullptr;
-        w.paths_cap = 0; w.shard_cap = 0;
+    if (cap > l.shard_cap) {
+        PT_HIP_CHECK(hipStreamSynchronize(l.stream));   // earlier work of this lane still uses the old queues
+        for (int a = 0; a < 2; ++a) for (int k = 0; k < 4; ++k) { (void)hipFree(l.q[a][k]); l.q[a][k] = nullptr; }
+        (void)hipFree(l.hits); (void)hipFree(l.path_result); l.hits = nullptr; l.path_result = nullptr;
+        l.paths_cap = 0; l.shard_cap = 0;
         const uint64_t slots = cap * kShards;
-        for (int a = 0; a < 2; ++a) for (int k = 0; k < 4; ++k) PT_HIP_CHECK(hipMalloc((void**)&w.q[a][k], sizeof(float4) * slots));
-        PT_HIP_CHECK(hipMalloc((void**)&w.hits, sizeof(PtHit) * slots));
-        PT_HIP_CHECK(hipMalloc((void**)&w.path_result, sizeof(float4) * slots));
-        w.paths_cap = slots; w.shard_cap = (uint32_t)cap;
+        for (int a = 0; a < 2; ++a) for (int k = 0; k < 4; ++k) PT_HIP_CHECK(hipMalloc((void**)&l.q[a][k], sizeof(float4) * slots));
+        PT_HIP_CHECK(hipMalloc((void**)&l.hits, sizeof(PtHit) * slots));
+        PT_HIP_CHECK(hipMalloc((void**)&l.path_result, sizeof(float4) * slots));
+        l.paths_cap = slots; l.shard_cap = (uint32_t)cap;
     }
     if (pixels > w.frame_pixels_cap) {
+        int rc = pt_lanes_sync(ctx);                    // frames in flight write the old image
+        if (rc) return rc;
         (void)hipFree(w.frame_result); w.frame_result = nullptr; w.frame_pixels_cap = 0;
         PT_HIP_CHECK(hipMalloc((void**)&w.frame_result, sizeof(float) * 3 * pixels));
         w.frame_pixels_cap = pixels;
@@ -453,7 +460,8 @@ int ensure_shade_records(PtContext* ctx, const PtTlas* tlas_c)
             r.tex.z = bits(td.width); r.tex.w = bits(td.height);
         }
     }
-    PT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    int rc = pt_lanes_sync(ctx);
+    if (rc) return rc;
     PT_HIP_CHECK(hipMemcpy(t->shade_inst, rec.data(), sizeof(PtDevShadeInstance) * t->n, hipMemcpyHostToDevice));
     t->shade_version = ctx->tables_version;
     return PT_OK;
@@ -477,10 +485,12 @@ int pt_intersect(PtContext* ctx, const PtTlas* tlas, uint32_t n, const float* or
     PT_REQUIRE(tlas->ctx == ctx, "the TLAS belongs to another context");
     if (n == 0) return PT_OK;
     PT_HIP_CHECK(hipSetDevice(ctx->device));
-    int rc = ensure_workspace(ctx, n, 0);
+    PtLane* lane = nullptr;
+    int rc = pt_lane_begin(ctx, &lane);
     if (rc) return rc;
-    PtWorkspace& w = ctx->ws;
-    hipStream_t st = ctx->stream;
+    PtLane& w = *lane;
+    if ((rc = ensure_workspace(ctx, w, n, 0))) return rc;
+    hipStream_t st = w.stream;
     PT_HIP_CHECK(hipMemsetAsync(w.counters, 0, sizeof(uint32_t) * kCounterWords, st));
     k_pack_rays<<<(n + kBlock - 1) / kBlock, kBlock, 0, st>>>(n, w.shard_cap, origins_dev, dirs_dev, w.q[0][0], w.q[0][1], w.counters);
     if (ctx->traversal_mode == 0) {
@@ -493,7 +503,7 @@ int pt_intersect(PtContext* ctx, const PtTlas* tlas, uint32_t n, const float* or
                                                            tmin, tmax, hits_dev, t_dev, w.spill);
     }
     PT_HIP_CHECK(hipGetLastError());
-    return PT_OK;
+    return pt_lanes_join(ctx);   // the hit records are ordered on the caller's stream
 }
 
 int pt_trace(PtContext* ctx, const PtTlas* tlas, const float camera[32], uint32_t width, uint32_t height,
@@ -514,21 +524,25 @@ int pt_trace(PtContext* ctx, const PtTlas* tlas, const float camera[32], uint32_
     if (chunk_pixels < 1) chunk_pixels = 1;
     if (chunk_pixels > n_pixels) chunk_pixels = n_pixels;
     PT_REQUIRE(chunk_pixels * spp < (1ull << 31), "max_paths too large");
-    rc = ensure_workspace(ctx, chunk_pixels * spp, n_pixels);
-    if (rc) return rc;
-    PtWorkspace& w = ctx->ws;
-    hipStream_t st = ctx->stream;
-    PT_HIP_CHECK(hipMemcpyAsync(w.cam, camera, sizeof(float) * 32, hipMemcpyHostToDevice, st));
     const PtTlasView tv = view_of(tlas);
+    PtCameraArg cam_arg;
+    memcpy(cam_arg.m, camera, sizeof cam_arg.m);
     const int blocks_i = ctx->traversal_mode == 0 ? persistent_blocks(ctx, (const void*)k_intersect<false>)
                                                   : persistent_blocks(ctx, (const void*)k_intersect_sched<false>);
     const int blocks_s = persistent_blocks(ctx, (const void*)k_shade);
+    // Every chunk of the frame goes to the next lane and is left in flight there; only the
+    // read-modify-write of the image is chained, in submission order.
     for (uint64_t p0 = 0; p0 < n_pixels; p0 += chunk_pixels) {
         const uint32_t np = (uint32_t)((n_pixels - p0) < chunk_pixels ? (n_pixels - p0) : chunk_pixels);
         const uint32_t n_paths = np * spp;
+        PtLane* lane = nullptr;
+        if ((rc = pt_lane_begin(ctx, &lane))) return rc;
+        PtLane& w = *lane;
+        if ((rc = ensure_workspace(ctx, w, (uint64_t)n_paths, n_pixels))) return rc;
+        hipStream_t st = w.stream;
         PT_HIP_CHECK(hipMemsetAsync(w.counters, 0, sizeof(uint32_t) * kCounterWords, st));
         k_generate<<<(n_paths + kBlock - 1) / kBlock, kBlock, 0, st>>>(n_paths, (uint32_t)p0, spp, width, height, frame, seed_mode, w.shard_cap,
-                                                                      w.cam, w.q[0][0], w.q[0][1], w.q[0][2], w.q[0][3], w.counters);
+                                                                      cam_arg, w.q[0][0], w.q[0][1], w.q[0][2], w.q[0][3], w.counters);
         for (uint32_t d = 0; d < max_depth; ++d) {
             const int a = d & 1, b = a ^ 1;
             hipEvent_t ev_stop = nullptr;
@@ -553,8 +567,12 @@ int pt_trace(PtContext* ctx, const PtTlas* tlas, const float camera[32], uint32_
                                                  w.q[a][0], w.q[a][1], w.q[a][2], w.q[a][3], w.q[b][0], w.q[b][1], w.q[b][2], w.q[b][3],
                                                  w.path_result);
         }
-        k_accumulate<<<(np + kBlock - 1) / kBlock, kBlock, 0, st>>>(np, (uint32_t)p0, spp, frame, accum_mode, w.path_result, w.frame_result, accum_dev);
-        k_stats<<<max_depth, 64, 0, st>>>(w.counters, max_depth, n_paths, w.stats);
+        if (ctx->last_accumulate && ctx->last_accumulate != lane)
+            PT_HIP_CHECK(hipStreamWaitEvent(st, ctx->last_accumulate->accumulated, 0));
+        k_accumulate<<<(np + kBlock - 1) / kBlock, kBlock, 0, st>>>(np, (uint32_t)p0, spp, frame, accum_mode, w.path_result, ctx->ws.frame_result, accum_dev);
+        PT_HIP_CHECK(hipEventRecord(w.accumulated, st));
+        ctx->last_accumulate = lane;
+        k_stats<<<max_depth, 64, 0, st>>>(w.counters, max_depth, n_paths, ctx->ws.stats);
     }
     PT_HIP_CHECK(hipGetLastError());
     ctx->last_w = width; ctx->last_h = height;
@@ -565,8 +583,8 @@ int pt_trace_last_result(PtContext* ctx, float* result_host)
 {
     PT_REQUIRE(ctx && result_host, "null argument");
     PT_REQUIRE(ctx->last_w && ctx->ws.frame_result, "no frame has been traced");
-    PT_HIP_CHECK(hipSetDevice(ctx->device));
-    PT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    int rc = pt_lanes_sync(ctx);
+    if (rc) return rc;
     PT_HIP_CHECK(hipMemcpy(result_host, ctx->ws.frame_result, sizeof(float) * 3 * (size_t)ctx->last_w * ctx->last_h, hipMemcpyDeviceToHost));
     return PT_OK;
 }
@@ -576,8 +594,8 @@ int pt_trace_stats(PtContext* ctx, PtTraceStats* out)
     PT_REQUIRE(ctx && out, "null argument");
     memset(out, 0, sizeof *out);
     if (!ctx->ws.stats) return PT_OK;
-    PT_HIP_CHECK(hipSetDevice(ctx->device));
-    PT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    int rc = pt_lanes_sync(ctx);
+    if (rc) return rc;
     uint64_t h[PT_MAX_DEPTH + 1];
     PT_HIP_CHECK(hipMemcpy(h, ctx->ws.stats, sizeof h, hipMemcpyDeviceToHost));
     for (int d = 0; d < PT_MAX_DEPTH; ++d) { out->rays_per_depth[d] = h[d]; out->rays += h[d]; }
@@ -596,8 +614,8 @@ int pt_trace_profile(PtContext* ctx, PtTraceProfile* out)
 {
     PT_REQUIRE(ctx && out, "null argument");
     memset(out, 0, sizeof *out);
-    PT_HIP_CHECK(hipSetDevice(ctx->device));
-    PT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    int rc = pt_lanes_sync(ctx);
+    if (rc) return rc;
     for (size_t k = 0; k + 1 < ctx->ev_used; k += 2) {
         float ms = 0.0f;
         PT_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev_pool[k], ctx->ev_pool[k + 1]));
@@ -617,7 +635,8 @@ int pt_trace_stats_reset(PtContext* ctx)
 {
     PT_REQUIRE(ctx, "null argument");
     if (!ctx->ws.stats) return PT_OK;
-    PT_HIP_CHECK(hipSetDevice(ctx->device));
+    int rc = pt_lanes_sync(ctx);
+    if (rc) return rc;
     PT_HIP_CHECK(hipMemsetAsync(ctx->ws.stats, 0, sizeof(uint64_t) * (PT_MAX_DEPTH + 1), ctx->stream));
     memset(ctx->stats_mark, 0, sizeof ctx->stats_mark);
     return PT_OK;
@@ -628,9 +647,20 @@ int pt_accum_resolve(PtContext* ctx, const float* accum_sum_dev, uint32_t n_pixe
     PT_REQUIRE(ctx && accum_sum_dev && rgba8_dev, "null argument");
     if (n_pixels == 0) return PT_OK;
     PT_HIP_CHECK(hipSetDevice(ctx->device));
+    int rc = pt_lanes_join(ctx);   // frames in flight still add to the sum
+    if (rc) return rc;
     k_resolve<<<(n_pixels + kBlock - 1) / kBlock, kBlock, 0, ctx->stream>>>(n_pixels, (const float4*)accum_sum_dev, (uchar4*)rgba8_dev, bgra);
     PT_HIP_CHECK(hipGetLastError());
     return PT_OK;
 }
 
 } // extern "C"
+
+#ifdef PT_SCHED_STATS
+extern "C" int pt_debug_sched_stats(unsigned long long* out8, int reset)
+{
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(pt_sched_stats), 64) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(pt_sched_stats), z, 64) != hipSuccess) return 1; }
+    return 0;
+}
+#endif

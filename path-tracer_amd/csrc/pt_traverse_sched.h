@@ -20,13 +20,34 @@
 #pragma once
 #include "pt_device.h"
 
-#define PT_SCHED_CHUNK 256u        // queue slots a wave claims per atomic
+#define PT_SCHED_CHUNK 256u        // most queue slots a wave claims per atomic (fewer when the queue is short)
+#ifndef PT_SCHED_REFILL
 #define PT_SCHED_REFILL 12         // refill when at least this many lanes are idle
+#endif
+#ifndef PT_SCHED_LEAF_VOTES
 #define PT_SCHED_LEAF_VOTES 20     // run the triangle phase once this many lanes wait in it ...
+#endif
+#ifndef PT_SCHED_ENTER_VOTES
 #define PT_SCHED_ENTER_VOTES 10    // ... the instance-entry phase at this many ...
+#endif
+#ifndef PT_SCHED_NODE_MIN
 #define PT_SCHED_NODE_MIN 24       // ... or when fewer than this many lanes want a box step
+#endif
+#ifndef PT_SCHED_NODE_STEPS
 #define PT_SCHED_NODE_STEPS 6      // box steps per vote while at least half the wave takes part
+#endif
+#ifndef PT_SCHED_LEAF_STEPS
 #define PT_SCHED_LEAF_STEPS 4      // triangles per vote while enough lanes take part
+#endif
+
+#ifdef PT_SCHED_STATS
+// development build: [0..2] iterations of the node / triangle / entry phase, [3..5] active lanes in them,
+// [6] outer loop iterations, [7] refill rounds
+__device__ unsigned long long pt_sched_stats[8];
+#define PT_STAT(i, v) do { if (lane == 0) atomicAdd(&pt_sched_stats[i], (unsigned long long)(v)); } while (0)
+#else
+#define PT_STAT(i, v) do { } while (0)
+#endif
 
 struct PtSchedQueue {              // the sharded queue of one bounce
     uint32_t* counters;
@@ -48,6 +69,9 @@ __device__ __forceinline__ void pt_traverse_sched(const PtTlasView& tl, const Pt
     uint32_t n_s = Q.counters[Q.count_base + (size_t)s * Q.ctr_pad];
     uint32_t wcur = 0, wend = 0;
     bool drained = false;
+    // a claim is a shard's fair share per wave, in whole batches: long queues amortise the atomic,
+    // short ones (deep bounces) still spread over all waves
+    const uint32_t waves_per_shard = max(1u, (gridDim.x * (PT_TRAVERSE_BLOCK / 64u)) / Q.n_shards);
 
     // ---- per-lane traversal state
     PtRaySpace cur;
@@ -92,12 +116,13 @@ __device__ __forceinline__ void pt_traverse_sched(const PtTlasView& tl, const Pt
                         if (n_s) {
                             uint32_t* work = &Q.counters[Q.work_base + (size_t)s * Q.ctr_pad];
                             if (__hip_atomic_load(work, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_s) {
+                                const uint32_t chunk = min(PT_SCHED_CHUNK, max(64u, (n_s / waves_per_shard + 63u) & ~63u));
                                 uint32_t base = 0;
-                                if (lane == 0) base = atomicAdd(work, PT_SCHED_CHUNK);
+                                if (lane == 0) base = atomicAdd(work, chunk);
                                 base = __builtin_amdgcn_readfirstlane(base);
                                 if (base < n_s) {
                                     wcur = s * Q.shard_cap + base;
-                                    wend = s * Q.shard_cap + (base + PT_SCHED_CHUNK < n_s ? base + PT_SCHED_CHUNK : n_s);
+                                    wend = s * Q.shard_cap + (base + chunk < n_s ? base + chunk : n_s);
                                     got = true;
                                     break;
                                 }
@@ -142,9 +167,11 @@ __device__ __forceinline__ void pt_traverse_sched(const PtTlasView& tl, const Pt
         else if (n_node > 0) phase = 0;
         else phase = n_leaf >= n_enter ? 1 : 2;
 
+        PT_STAT(6, 1);
         if (phase == 0) {
             int steps = PT_SCHED_NODE_STEPS;
             do {
+                { const int act_ = __popcll(__ballot(want_node)); (void)act_; PT_STAT(0, 1); PT_STAT(3, act_); }
                 if (want_node) {
                     const int next = pt_wide_step(cur, tl.nodes, node, tlo, fminf(thi, best.t), stk);
                     if ((unsigned)next < (unsigned)PT_NODE_DONE) node = next; else advance(next);
@@ -155,6 +182,7 @@ __device__ __forceinline__ void pt_traverse_sched(const PtTlasView& tl, const Pt
         } else if (phase == 1) {
             int steps = PT_SCHED_LEAF_STEPS;
             do {
+                { const int act_ = __popcll(__ballot(want_leaf)); (void)act_; PT_STAT(1, 1); PT_STAT(4, act_); }
                 if (want_leaf) {
                     const uint32_t code = ~(uint32_t)node;
                     const uint32_t pos = code >> 3;
@@ -162,9 +190,8 @@ __device__ __forceinline__ void pt_traverse_sched(const PtTlasView& tl, const Pt
                     float t, u, v;
                     if (pt_tri_test(cur, delta, a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, t, u, v)) {
                         const uint32_t prim = __float_as_uint(c.y);
-                        if (t > tmin && t < tmax && t >= tlo && t <= thi) {
+                        if (t > tmin && t < tmax && t >= tlo && t <= thi)
                             pt_hit_update(best, t, cur_inst, prim, u, v);
-                        }
                     }
                     // one triangle per step: first + 1, count - 1
                     if (code & 7u) node = (int)~(code + 7u);
@@ -174,6 +201,7 @@ __device__ __forceinline__ void pt_traverse_sched(const PtTlasView& tl, const Pt
                 n_leaf = __popcll(__ballot(want_leaf));
             } while (--steps > 0 && n_leaf >= PT_SCHED_LEAF_VOTES / 2);
         } else {
+            PT_STAT(2, 1); PT_STAT(5, n_enter);
             if (want_enter) {
                 const uint32_t ii = tl.leaf_inst[(~(uint32_t)node) >> 3];
                 const float4* q = tl.inst[ii].q;

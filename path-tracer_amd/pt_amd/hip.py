@@ -32,6 +32,8 @@ SIGNATURES = {
     "pt_ctx_create": (_i, [_i, _vp, C.POINTER(_vp)]),
     "pt_ctx_destroy": (_i, [_vp]),
     "pt_sync": (_i, [_vp]),
+    "pt_ctx_set_frames_in_flight": (_i, [_vp, C.c_int]),
+    "pt_trace_fence": (_i, [_vp]),
     "pt_buffer_upload": (_i, [_vp, _vp, _sz, C.POINTER(_vp)]),
     "pt_buffer_download": (_i, [_vp, _vp, _sz, _vp]),
     "pt_buffer_free": (_i, [_vp, _vp]),
@@ -115,6 +117,13 @@ class Context:
 
     def sync(self):
         _check(self.lib.pt_sync(self.h))
+
+    def set_frames_in_flight(self, n):
+        _check(self.lib.pt_ctx_set_frames_in_flight(self.h, n))
+
+    def fence(self):
+        """The context's stream waits for every frame in flight (no host wait)."""
+        _check(self.lib.pt_trace_fence(self.h))
 
     def set_max_paths(self, n):
         _check(self.lib.pt_ctx_set_max_paths(self.h, n))
@@ -285,6 +294,10 @@ class Renderer:
         out = np.zeros(1, dtype=TRACE_STATS)
         _check(self.ctx.lib.pt_trace_stats(self.ctx.h, _p(out)))
         return out[0]
+
+    def fence(self):
+        """Orders everything traced so far before later work on the context's stream."""
+        self.ctx.fence()
 
     def set_profiling(self, enabled):
         _check(self.ctx.lib.pt_ctx_set_profiling(self.ctx.h, int(enabled)))
