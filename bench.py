@@ -108,8 +108,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # warmup (frames that are not part of the timed set)
-    run_steps(r, accum.data_ptr(), args.warmup, 1_000_000, rank, world, args.spp, args.max_depth)
+    # warmup (frames that are not part of the timed set); at least one step per frame in flight, so
+    # that every internal stream has allocated its path queues before the clock starts
+    run_steps(r, accum.data_ptr(), max(args.warmup, args.frames_in_flight), 1_000_000, rank, world, args.spp, args.max_depth)
     r.ctx.sync()                    # frames in flight still add to the image
     accum.zero_()
     r.reset_stats()
@@ -197,7 +198,7 @@ def main():
             r.close()
             c = hip.Renderer(build_scene("cornell"), W, H, device=local_rank, stream=stream)
             acc2 = torch.zeros(H * W * 4, dtype=torch.float32, device="cuda")
-            run_steps(c, acc2.data_ptr(), 1, 1_000_000, 0, 1, args.spp, args.max_depth)
+            run_steps(c, acc2.data_ptr(), 3, 1_000_000, 0, 1, args.spp, args.max_depth)
             c.reset_stats()
             torch.cuda.synchronize()
             t1 = time.perf_counter()

@@ -172,8 +172,8 @@ struct PtStack {
 };
 
 // One step through a 64-byte 4-wide node with child boxes quantised to 8 bits on the node's own
-// grid: (origin.xyz, exponents) (child[0..3]) (lo.x lo.y lo.z hi.x words) (hi.y hi.z words, -, -);
-// byte k of each word belongs to child k and a plane is fma(byte, 2^exponent, origin).
+// grid: (origin.xyz, step.x) (child[0..3]) (lo.x lo.y lo.z hi.x words) (hi.y hi.z words, step.y, step.z);
+// byte k of each word belongs to child k and a plane is fma(byte, step, origin).
 // Continues with the nearest child that the ray interval [tlo, hi] overlaps and pushes the others
 // so that nearer ones are popped first; returns the next item (a pop if nothing was hit).
 __device__ __forceinline__ int pt_wide_step(const PtRaySpace& r, const float4* __restrict__ nodes, int node,
@@ -181,10 +181,7 @@ __device__ __forceinline__ int pt_wide_step(const PtRaySpace& r, const float4* _
 {
     const float4 h0 = nodes[4 * (size_t)node + 0], h1 = nodes[4 * (size_t)node + 1];
     const float4 h2 = nodes[4 * (size_t)node + 2], h3 = nodes[4 * (size_t)node + 3];
-    const uint32_t exps = __float_as_uint(h0.w);
-    const float sx = __uint_as_float((exps & 255u) << 23);
-    const float sy = __uint_as_float(((exps >> 8) & 255u) << 23);
-    const float sz = __uint_as_float(((exps >> 16) & 255u) << 23);
+    const float sx = h0.w, sy = h3.z, sz = h3.w;
     const uint32_t Lx = __float_as_uint(h2.x), Ly = __float_as_uint(h2.y), Lz = __float_as_uint(h2.z);
     const uint32_t Hx = __float_as_uint(h2.w), Hy = __float_as_uint(h3.x), Hz = __float_as_uint(h3.y);
     const int ref_in[4] = { __float_as_int(h1.x), __float_as_int(h1.y), __float_as_int(h1.z), __float_as_int(h1.w) };

@@ -18,16 +18,20 @@
 // against can grow but the closest hit cannot change.
 struct PtWide4 {
     float origin[3];
-    uint32_t exps;          // biased binary32 exponents of the grid step: x | y << 8 | z << 16
+    float scale_x;          // grid steps are powers of two
     int32_t child[4];       // >= 0 wide node, < 0 leaf (~c = first << 3 | count - 1), INT32_MIN empty
     uint32_t q[6];          // lo.x, lo.y, lo.z, hi.x, hi.y, hi.z; byte k of each word belongs to child k
-    uint32_t pad[2];
+    float scale_y, scale_z;
 };
 static_assert(sizeof(PtWide4) == 64, "wide node must be 64 bytes");
 
-static inline float pt_grid_plane(uint32_t q, uint32_t exp_byte, float origin)
+static inline float pt_grid_scale(uint32_t exp_byte)
 {
     uint32_t bits = exp_byte << 23; float scale; memcpy(&scale, &bits, 4);
+    return scale;
+}
+static inline float pt_grid_plane(uint32_t q, float scale, float origin)
+{
     return __builtin_fmaf((float)q, scale, origin);
 }
 
@@ -85,23 +89,23 @@ static inline uint32_t pt_collapse_to_wide(const std::vector<PtBvhNode>& n2, uin
                     uint32_t bits = (uint32_t)eb << 23; float scale; memcpy(&scale, &bits, 4);
                     double qh = ceil(((double)ent[e].hi[k] - (double)lo[k]) / (double)scale);
                     if (qh > 255.0) ok = false;
-                    else { uint32_t q = (uint32_t)(qh < 0 ? 0 : qh); while (q <= 255 && pt_grid_plane(q, (uint32_t)eb, lo[k]) < ent[e].hi[k]) ++q; if (q > 255) ok = false; }
+                    else { uint32_t q = (uint32_t)(qh < 0 ? 0 : qh); while (q <= 255 && pt_grid_plane(q, scale, lo[k]) < ent[e].hi[k]) ++q; if (q > 255) ok = false; }
                 }
                 if (ok || eb >= 254) break;
             }
             ex[k] = (uint32_t)eb;
         }
-        w.exps = ex[0] | (ex[1] << 8) | (ex[2] << 16);
+        w.scale_x = pt_grid_scale(ex[0]); w.scale_y = pt_grid_scale(ex[1]); w.scale_z = pt_grid_scale(ex[2]);
         for (int e = 0; e < 4; ++e) w.child[e] = EMPTY;
         for (int e = 0; e < ne; ++e) {
             for (int k = 0; k < 3; ++k) {
                 uint32_t bits = ex[k] << 23; float scale; memcpy(&scale, &bits, 4);
                 double ql = floor(((double)ent[e].lo[k] - (double)lo[k]) / (double)scale);
                 uint32_t q_lo = (uint32_t)(ql < 0 ? 0 : (ql > 255 ? 255 : ql));
-                while (q_lo > 0 && pt_grid_plane(q_lo, ex[k], lo[k]) > ent[e].lo[k]) --q_lo;
+                while (q_lo > 0 && pt_grid_plane(q_lo, scale, lo[k]) > ent[e].lo[k]) --q_lo;
                 double qh = ceil(((double)ent[e].hi[k] - (double)lo[k]) / (double)scale);
                 uint32_t q_hi = (uint32_t)(qh < 0 ? 0 : (qh > 255 ? 255 : qh));
-                while (q_hi < 255 && pt_grid_plane(q_hi, ex[k], lo[k]) < ent[e].hi[k]) ++q_hi;
+                while (q_hi < 255 && pt_grid_plane(q_hi, scale, lo[k]) < ent[e].hi[k]) ++q_hi;
                 w.q[k] |= q_lo << (8 * e);
                 w.q[3 + k] |= q_hi << (8 * e);
             }

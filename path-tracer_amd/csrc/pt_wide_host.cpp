@@ -41,9 +41,9 @@ uint32_t pt_wide_candidates_host(const void* wide, uint32_t root, const float o[
             if (w.child[e] == EMPTY) continue;
             float tn = -std::numeric_limits<float>::infinity(), tf = std::numeric_limits<float>::infinity();
             for (int k = 0; k < 3; ++k) {
-                const uint32_t ex = (w.exps >> (8 * k)) & 255u;
-                const float lo = pt_grid_plane((w.q[k] >> (8 * e)) & 255u, ex, w.origin[k]);
-                const float hi = pt_grid_plane((w.q[3 + k] >> (8 * e)) & 255u, ex, w.origin[k]);
+                const float sc = k == 0 ? w.scale_x : (k == 1 ? w.scale_y : w.scale_z);
+                const float lo = pt_grid_plane((w.q[k] >> (8 * e)) & 255u, sc, w.origin[k]);
+                const float hi = pt_grid_plane((w.q[3 + k] >> (8 * e)) & 255u, sc, w.origin[k]);
                 const float a = __builtin_fmaf(lo, inv[k], -oo[k]), b = __builtin_fmaf(hi, inv[k], -oo[k]);
                 tn = fmaxf(tn, fminf(a, b)); tf = fminf(tf, fmaxf(a, b));
             }

@@ -225,6 +225,30 @@ def test_accumulation_modes(mode, cornell):
         r.close()
 
 
+@pytest.mark.parametrize("mode", [0, 2])
+def test_frames_in_flight_keep_submission_order(mode, cornell):
+    """Several frames (and several pixel chunks per frame) in flight on the library's internal
+    streams give the image of strictly serial frames, bit for bit, also for the order-dependent
+    8-bit running mean."""
+    w = h = 256
+    images = {}
+    for lanes in (1, 3):
+        r = _renderer(cornell, w, h)
+        try:
+            r.ctx.set_frames_in_flight(lanes)
+            r.ctx.set_max_paths(100_000)          # three chunks per frame
+            for frame in range(5):
+                r.render(spp=4, frame=frame, accum_mode=mode)
+            images[lanes] = r.accum_host().copy()
+            assert int(r.stats()["paths"]) == 5 * w * h * 4
+        finally:
+            r.close()
+    if mode == 2:
+        assert np.array_equal(images[1], images[3])
+    else:
+        assert _float_eq(images[1], images[3])
+
+
 def test_full_size_properties_1080p(dragon):
     """BASELINE size (1080p): properties that need no oracle run -- every path accounted for,
     one primary ray per path, monotone ray counts per bounce, finite non-negative radiance,

@@ -17,7 +17,7 @@ from pt_amd import abi
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(ROOT, "path-tracer_amd", "lib", "libpt_wide_host.so")
 
-WIDE4 = np.dtype([("origin", "<f4", 3), ("exps", "<u4"), ("child", "<i4", 4), ("q", "<u4", 6), ("pad", "<u4", 2)])
+WIDE4 = np.dtype([("origin", "<f4", 3), ("scale_x", "<f4"), ("child", "<i4", 4), ("q", "<u4", 6), ("scale_y", "<f4"), ("scale_z", "<f4")])
 EMPTY = -2**31
 
 
@@ -46,7 +46,9 @@ def collapse(lib, nodes, tri_base=0):
 def entry_box(w, e):
     lo, hi = np.zeros(3, np.float32), np.zeros(3, np.float32)
     for k in range(3):
-        scale = np.array([((int(w["exps"]) >> (8 * k)) & 255) << 23], np.uint32).view(np.float32)[0]
+        scale = w[("scale_x", "scale_y", "scale_z")[k]]
+        m, _ = np.frexp(np.float64(scale))
+        assert m == 0.5 and scale > 0          # a power of two
         ql = (int(w["q"][k]) >> (8 * e)) & 255
         qh = (int(w["q"][3 + k]) >> (8 * e)) & 255
         # q * scale + origin is exact in binary64, so one rounding to binary32 equals the fma
