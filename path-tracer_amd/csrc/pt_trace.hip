@@ -14,9 +14,10 @@
 // Ray queues are split into kShards independent shards, each with its own size and work counter
 // on its own 128-byte line.  A single queue head saturates at roughly 90 atomics per microsecond,
 // which for 33 M rays (half a million 64-ray batches) costs more than the traversal itself;
-// 64 heads remove that limit.  Kernels run on a fixed persistent grid: every wave starts at the
-// shard matching its index, pulls 64-slot batches with one atomic each and moves on to the next
-// shard when one runs dry, so sizes stay on the device and a frame needs no host round trip.
+// 64 heads remove that limit.  Traversal runs on a fixed persistent grid: every wave starts at the
+// shard matching its index, claims slots with one atomic per few batches and moves on to the next
+// shard when one runs dry.  Shading is launched with one wave per batch of the fullest possible
+// shard.  Either way sizes stay on the device and a frame needs no host round trip.
 // Survivors of shard s go to shard s of the next queue, which therefore never overflows.
 #include "pt_device.h"
 #include "pt_traverse_sched.h"
@@ -29,10 +30,10 @@ namespace {
 #endif
 constexpr int kBlock = 256;
 static_assert(kBlock == PT_TRAVERSE_BLOCK, "traversal stack stride");
-constexpr int kShards = 64;
+constexpr int kShards = 64;                              // one per lane: the traversal kernels scan them with one load per lane
 constexpr int kCtrPad = 32;                              // uint32 slots per counter: one 128-byte line each
 constexpr int kCtrPerKind = (PT_MAX_DEPTH + 1) * kShards;
-enum { CTR_COUNT = 0, CTR_WORK_INTERSECT = 1, CTR_WORK_SHADE = 2, CTR_KINDS = 3 };
+enum { CTR_COUNT = 0, CTR_WORK_INTERSECT = 1, CTR_KINDS = 2 };
 constexpr size_t kCounterWords = (size_t)CTR_KINDS * kCtrPerKind * kCtrPad;
 
 __host__ __device__ inline size_t ctr_index(int kind, uint32_t depth, uint32_t shard)
@@ -56,12 +57,20 @@ __device__ __forceinline__ uint32_t shard_count(uint32_t n, uint32_t s)
 }
 
 // Calls body(slot index, valid, shard) for every 64-slot batch of one queue level.
-template <typename Body>
+// FLAT: the grid has one wave per batch of the fullest shard (wave g: shard g % kShards, batch
+// g / kShards) instead of a persistent grid that claims batches; for levels known to be full.
+template <bool FLAT, typename Body>
 __device__ __forceinline__ void for_each_batch(uint32_t* __restrict__ counters, int work_kind, uint32_t depth,
                                                uint32_t shard_cap, Body body)
 {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (FLAT) {
+        const uint32_t s = wave % kShards, base = (wave / kShards) * 64u;
+        const uint32_t n_s = counters[ctr_index(CTR_COUNT, depth, s)];
+        if (base < n_s) body(s * shard_cap + base + lane, base + lane < n_s, s);
+        return;
+    }
     for (uint32_t k = 0; k < kShards; ++k) {
         const uint32_t s = (wave + k) & (kShards - 1);
         const uint32_t n_s = counters[ctr_index(CTR_COUNT, depth, s)];
@@ -85,7 +94,7 @@ struct PtCameraArg { float m[32]; };
 __global__ void __launch_bounds__(kBlock)
 k_generate(uint32_t n_paths, uint32_t pixel0, uint32_t spp, uint32_t W, uint32_t H, uint32_t frame, uint32_t seed_mode,
            uint32_t shard_cap, PtCameraArg camera /* viewInverse, projInverse; by value: no copy to wait for */, float4* __restrict__ q0,
-           float4* __restrict__ q1, float4* __restrict__ q2, float4* __restrict__ q3, uint32_t* __restrict__ counters)
+           float4* __restrict__ q1, uint32_t* __restrict__ counters)
 {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q < kShards) counters[ctr_index(CTR_COUNT, 0, q)] = shard_count(n_paths, q);
@@ -108,8 +117,7 @@ k_generate(uint32_t n_paths, uint32_t pixel0, uint32_t spp, uint32_t W, uint32_t
     const uint32_t i = slot_of_path(q, shard_cap);
     q0[i] = make_float4(VI[12], VI[13], VI[14], __uint_as_float(seed));
     q1[i] = make_float4(rx, ry, rz, __uint_as_float(q));
-    q2[i] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
-    q3[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    // currentWeight = 1 and hitValue = 0 (ray_gen.rgen:44-48) are not stored: the first shade pass knows them
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -124,7 +132,7 @@ k_intersect(PtTlasView tl, uint32_t* __restrict__ counters, uint32_t depth, uint
     PtStack stk;
     stk.lds = (pt_lds_int*)&s_stack[0][threadIdx.x];
     stk.spill_base = spill;
-    for_each_batch(counters, CTR_WORK_INTERSECT, depth, shard_cap, [&](uint32_t i, bool valid, uint32_t) {
+    for_each_batch<false>(counters, CTR_WORK_INTERSECT, depth, shard_cap, [&](uint32_t i, bool valid, uint32_t) {
         if (valid) {
             const float4 o = q0[i], d = q1[i];
             PtHitRec h;
@@ -201,7 +209,16 @@ __device__ __forceinline__ void pt_texture_rgb(const uint32_t* __restrict__ texe
     r = out[0]; g = out[1]; b = out[2];
 }
 
-__global__ void __launch_bounds__(kBlock)
+// FIRST: bounce 0, where the path weight is 1 and the collected radiance 0 and neither is read.
+// Launched with one wave per batch of the fullest shard rather than as a persistent grid: a shard
+// never holds more than at bounce 0, so the bounce-0 grid covers every level and waves past a
+// shard's end leave at once.  (Claiming batches one atomic at a time cost a persistent shade pass
+// two thirds of its time.)
+#ifndef PT_SHADE_WAVES
+#define PT_SHADE_WAVES 4
+#endif
+template <bool FIRST>
+__global__ void __launch_bounds__(kBlock, PT_SHADE_WAVES)
 k_shade(const PtDevShadeInstance* __restrict__ shade_inst, uint32_t depth, uint32_t max_depth,
         uint32_t* __restrict__ counters, uint32_t shard_cap, const PtHit* __restrict__ hits,
         const float4* __restrict__ q0, const float4* __restrict__ q1, const float4* __restrict__ q2, const float4* __restrict__ q3,
@@ -210,15 +227,15 @@ k_shade(const PtDevShadeInstance* __restrict__ shade_inst, uint32_t depth, uint3
 {
     const uint32_t lane = threadIdx.x & 63;
     const float PI_F = 3.14159265f;
-    for_each_batch(counters, CTR_WORK_SHADE, depth, shard_cap, [&](uint32_t i, bool valid, uint32_t shard) {
+    for_each_batch<true>(counters, CTR_COUNT, depth, shard_cap, [&](uint32_t i, bool valid, uint32_t shard) {
         bool alive = false;
         float4 no, nd, nw, nh;
         if (valid) {
             const PtHit h = hits[i];
             const uint32_t seed_in = __float_as_uint(q0[i].w);
             const uint32_t path = __float_as_uint(q1[i].w);
-            const float4 cw = q2[i];
-            float4 hv = q3[i];
+            const float4 cw = FIRST ? make_float4(1.0f, 1.0f, 1.0f, 0.0f) : q2[i];
+            float4 hv = FIRST ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : q3[i];
             if (h.instance == 0xFFFFFFFFu) {
                 // miss.rmiss:10-20
                 const float e = depth == 0 ? 1.0f * 0.8f : 0.01f;
@@ -231,7 +248,19 @@ k_shade(const PtDevShadeInstance* __restrict__ shade_inst, uint32_t depth, uint3
                 const PtVertex* vertices = (const PtVertex*)ptr_from(ptrs.x, ptrs.y);
                 const uint32_t* indices = (const uint32_t*)ptr_from(ptrs.z, ptrs.w);
                 const uint32_t ia = indices[3 * (size_t)h.primitive + 0], ib = indices[3 * (size_t)h.primitive + 1], ic = indices[3 * (size_t)h.primitive + 2];
-                const PtVertex A = vertices[ia], B = vertices[ib], C = vertices[ic];
+                PtVertex A, B, C;
+                if ((((uintptr_t)vertices) & 15u) == 0) {
+                    // 32-byte vertices on a 16-byte boundary: two 16-byte loads each instead of eight dwords
+                    const float4* v4 = (const float4*)vertices;
+                    const float4 a0 = v4[2 * (size_t)ia], a1 = v4[2 * (size_t)ia + 1];
+                    const float4 b0_ = v4[2 * (size_t)ib], b1_ = v4[2 * (size_t)ib + 1];
+                    const float4 c0 = v4[2 * (size_t)ic], c1 = v4[2 * (size_t)ic + 1];
+                    A = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
+                    B = { b0_.x, b0_.y, b0_.z, b0_.w, b1_.x, b1_.y, b1_.z, b1_.w };
+                    C = { c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w };
+                } else {
+                    A = vertices[ia]; B = vertices[ib]; C = vertices[ic];
+                }
                 const float b0 = 1.0f - h.u - h.v, b1 = h.u, b2 = h.v;
 #define PT_MIX3(x, y, z) PT_FMA((z), b2, PT_FMA((y), b1, (x) * b0))
                 float px = PT_MIX3(A.px, B.px, C.px), py = PT_MIX3(A.py, B.py, C.py), pz = PT_MIX3(A.pz, B.pz, C.pz);
@@ -529,7 +558,6 @@ int pt_trace(PtContext* ctx, const PtTlas* tlas, const float camera[32], uint32_
     memcpy(cam_arg.m, camera, sizeof cam_arg.m);
     const int blocks_i = ctx->traversal_mode == 0 ? persistent_blocks(ctx, (const void*)k_intersect<false>)
                                                   : persistent_blocks(ctx, (const void*)k_intersect_sched<false>);
-    const int blocks_s = persistent_blocks(ctx, (const void*)k_shade);
     // Every chunk of the frame goes to the next lane and is left in flight there; only the
     // read-modify-write of the image is chained, in submission order.
     for (uint64_t p0 = 0; p0 < n_pixels; p0 += chunk_pixels) {
@@ -540,9 +568,11 @@ int pt_trace(PtContext* ctx, const PtTlas* tlas, const float camera[32], uint32_
         PtLane& w = *lane;
         if ((rc = ensure_workspace(ctx, w, (uint64_t)n_paths, n_pixels))) return rc;
         hipStream_t st = w.stream;
+        // one wave per batch of the fullest shard at bounce 0
+        const uint32_t blocks_flat = (uint32_t)((((uint64_t)n_paths + 63) / 64 + kShards - 1) / kShards * kShards + kBlock / 64 - 1) / (kBlock / 64);
         PT_HIP_CHECK(hipMemsetAsync(w.counters, 0, sizeof(uint32_t) * kCounterWords, st));
         k_generate<<<(n_paths + kBlock - 1) / kBlock, kBlock, 0, st>>>(n_paths, (uint32_t)p0, spp, width, height, frame, seed_mode, w.shard_cap,
-                                                                      cam_arg, w.q[0][0], w.q[0][1], w.q[0][2], w.q[0][3], w.counters);
+                                                                      cam_arg, w.q[0][0], w.q[0][1], w.counters);
         for (uint32_t d = 0; d < max_depth; ++d) {
             const int a = d & 1, b = a ^ 1;
             hipEvent_t ev_stop = nullptr;
@@ -563,9 +593,11 @@ int pt_trace(PtContext* ctx, const PtTlas* tlas, const float camera[32], uint32_
                 k_intersect_sched<false><<<blocks_i, kBlock, 0, st>>>(tv, w.counters, d, w.shard_cap, w.q[a][0], w.q[a][1],
                                                                       0.001f, 10000.0f, w.hits, nullptr, w.spill);
             if (ev_stop) PT_HIP_CHECK(hipEventRecord(ev_stop, st));
-            k_shade<<<blocks_s, kBlock, 0, st>>>(tlas->shade_inst, d, max_depth, w.counters, w.shard_cap, w.hits,
-                                                 w.q[a][0], w.q[a][1], w.q[a][2], w.q[a][3], w.q[b][0], w.q[b][1], w.q[b][2], w.q[b][3],
-                                                 w.path_result);
+#define PT_SHADE_ARGS tlas->shade_inst, d, max_depth, w.counters, w.shard_cap, w.hits, w.q[a][0], w.q[a][1], w.q[a][2], w.q[a][3], \
+                      w.q[b][0], w.q[b][1], w.q[b][2], w.q[b][3], w.path_result
+            if (d == 0) k_shade<true><<<blocks_flat, kBlock, 0, st>>>(PT_SHADE_ARGS);
+            else k_shade<false><<<blocks_flat, kBlock, 0, st>>>(PT_SHADE_ARGS);
+#undef PT_SHADE_ARGS
         }
         if (ctx->last_accumulate && ctx->last_accumulate != lane)
             PT_HIP_CHECK(hipStreamWaitEvent(st, ctx->last_accumulate->accumulated, 0));

@@ -64,11 +64,16 @@ __device__ __forceinline__ void pt_traverse_sched(const PtTlasView& tl, const Pt
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
-    // ---- wave-uniform work cursor
-    uint32_t shard_iter = 0, s = wave & (Q.n_shards - 1);
-    uint32_t n_s = Q.counters[Q.count_base + (size_t)s * Q.ctr_pad];
+    // ---- wave-uniform work cursor.  Lane s looks at shard s once (the queue only shrinks while the
+    // kernel runs); shards with work left are the set bits of `avail`, visited round-robin from the
+    // wave's own shard, so a drained level costs one round trip instead of one per shard.
+    const uint32_t ns_lane = lane < Q.n_shards ? Q.counters[Q.count_base + (size_t)lane * Q.ctr_pad] : 0u;
+    const uint32_t wk_lane = lane < Q.n_shards
+        ? __hip_atomic_load(&Q.counters[Q.work_base + (size_t)lane * Q.ctr_pad], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    unsigned long long avail = __ballot(wk_lane < ns_lane);
+    const uint32_t start = wave & 63u;
     uint32_t wcur = 0, wend = 0;
-    bool drained = false;
+    bool drained = avail == 0ull;
     // a claim is a shard's fair share per wave, in whole batches: long queues amortise the atomic,
     // short ones (deep bounces) still spread over all waves
     const uint32_t waves_per_shard = max(1u, (gridDim.x * (PT_TRAVERSE_BLOCK / 64u)) / Q.n_shards);
@@ -112,30 +117,28 @@ __device__ __forceinline__ void pt_traverse_sched(const PtTlasView& tl, const Pt
             while (idle) {
                 if (wcur == wend) {
                     bool got = false;
-                    while (shard_iter < Q.n_shards) {
-                        if (n_s) {
-                            uint32_t* work = &Q.counters[Q.work_base + (size_t)s * Q.ctr_pad];
-                            if (__hip_atomic_load(work, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_s) {
-                                const uint32_t chunk = min(PT_SCHED_CHUNK, max(64u, (n_s / waves_per_shard + 63u) & ~63u));
-                                uint32_t base = 0;
-                                if (lane == 0) base = atomicAdd(work, chunk);
-                                base = __builtin_amdgcn_readfirstlane(base);
-                                if (base < n_s) {
-                                    wcur = s * Q.shard_cap + base;
-                                    wend = s * Q.shard_cap + (base + chunk < n_s ? base + chunk : n_s);
-                                    got = true;
-                                    break;
-                                }
-                            }
+                    while (avail) {
+                        // next shard with work at or after the wave's own
+                        const unsigned long long rot = start ? ((avail >> start) | (avail << (64u - start))) : avail;
+                        const uint32_t s = ((uint32_t)__builtin_ctzll(rot) + start) & 63u;
+                        const uint32_t n_s = __builtin_amdgcn_readlane(ns_lane, s);
+                        uint32_t* work = &Q.counters[Q.work_base + (size_t)s * Q.ctr_pad];
+                        const uint32_t chunk = min(PT_SCHED_CHUNK, max(64u, (n_s / waves_per_shard + 63u) & ~63u));
+                        uint32_t base = 0;
+                        if (lane == 0) base = atomicAdd(work, chunk);
+                        base = __builtin_amdgcn_readfirstlane(base);
+                        if (base < n_s) {
+                            wcur = s * Q.shard_cap + base;
+                            wend = s * Q.shard_cap + (base + chunk < n_s ? base + chunk : n_s);
+                            got = true;
+                            break;
                         }
-                        ++shard_iter;
-                        s = (wave + shard_iter) & (Q.n_shards - 1);
-                        n_s = Q.counters[Q.count_base + (size_t)s * Q.ctr_pad];
+                        avail &= ~(1ull << s);
                     }
                     if (!got) { drained = true; break; }
                 }
-                const uint32_t n_idle = __popcll(idle), avail = wend - wcur;
-                const uint32_t take = n_idle < avail ? n_idle : avail;
+                const uint32_t n_idle = __popcll(idle), left = wend - wcur;
+                const uint32_t take = n_idle < left ? n_idle : left;
                 const uint32_t rank = __popcll(idle & lt_mask);
                 if (node == PT_NODE_DONE && rank < take) {
                     qi = wcur + rank;
