@@ -25,6 +25,18 @@ sys.path.insert(0, os.path.join(ROOT, "path-tracer_amd"))
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 
 
+def measured_traffic(workload_key):
+    """HBM-side bytes per intersect launch from the committed PMC passes (profiles/traffic.json,
+    written by tools/pmc_traffic.py from separate FETCH_SIZE / WRITE_SIZE runs of this workload);
+    None when no pass was recorded for the workload."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            rec = json.load(f).get(workload_key)
+        return float(rec["bytes_per_launch"]) if rec else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def build_scene(name):
     from pt_amd import procedural
     from pt_amd.scene import Scene
@@ -179,7 +191,8 @@ def main():
         achieved = (i_rays * bytes_intersect) / (i_ms * 1e-3) / 1e9 if i_ms > 0 else 0.0
         out["roofline"] = {
             "bound": "hbm", "kernel": "k_intersect", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": measured_traffic(f"{args.scene} {W}x{H} {args.spp}spp depth{args.max_depth} lanes{args.frames_in_flight}"),
             "launches": i_n, "avg_launch_ms": i_ms / max(i_n, 1), "rays_per_launch": i_rays / max(i_n, 1),
             "frames_in_flight": args.frames_in_flight,
             "bytes_per_ray": bytes_intersect, "box_tests_per_ray": vn, "tri_tests_per_ray": vt,

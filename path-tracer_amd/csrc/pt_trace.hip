@@ -9,7 +9,8 @@
 // Path state lives in four float4 streams per queue slot (ping-pong between bounces):
 //   q0 = (origin.xyz, bits(seed))   q1 = (direction.xyz, bits(path id))
 //   q2 = (currentWeight.rgb, -)     q3 = (hitValue.rgb, -)
-// so every lane moves 16 bytes per access and a wave moves 1 KiB per instruction.
+// so every lane moves 16 bytes per access and a wave moves 1 KiB per instruction.  The "path id" is the
+// slot of the path's final radiance, laid out [sample][pixel of the chunk].
 //
 // Ray queues are split into kShards independent shards, each with its own size and work counter
 // on its own 128-byte line.  A single queue head saturates at roughly 90 atomics per microsecond,
@@ -116,7 +117,8 @@ k_generate(uint32_t n_paths, uint32_t pixel0, uint32_t spp, uint32_t W, uint32_t
     uint32_t seed = pt_tea(py * W + px, v1);
     const uint32_t i = slot_of_path(q, shard_cap);
     q0[i] = make_float4(VI[12], VI[13], VI[14], __uint_as_float(seed));
-    q1[i] = make_float4(rx, ry, rz, __uint_as_float(q));
+    // the path's result slot is sample-major, so that the per-pixel sum reads consecutive pixels together
+    q1[i] = make_float4(rx, ry, rz, __uint_as_float(s * (n_paths / spp) + q / spp));
     // currentWeight = 1 and hitValue = 0 (ray_gen.rgen:44-48) are not stored: the first shade pass knows them
 }
 
@@ -354,7 +356,7 @@ k_accumulate(uint32_t n_pixels, uint32_t pixel0, uint32_t spp, uint32_t frame, u
     if (p >= n_pixels) return;
     float r = 0.0f, g = 0.0f, b = 0.0f;
     for (uint32_t s = 0; s < spp; ++s) {
-        const float4 hv = path_result[(size_t)p * spp + s];
+        const float4 hv = path_result[(size_t)s * n_pixels + p];
         r = PT_FMA(hv.x, 2.5f, r); g = PT_FMA(hv.y, 2.5f, g); b = PT_FMA(hv.z, 2.5f, b);
     }
     const float fs = (float)spp;

@@ -1,4 +1,5 @@
-// pt_wide.h -- host-side construction of the traversal layout (plain C++, no device code).
+// pt_wide.h -- construction of the traversal layout: per-node routines shared by the GPU builder
+// (pt_build.hip) and a host-side breadth-first collapse (plain C++) that CPU tests check it against.
 #pragma once
 #include "../../include/pt_hip.h"
 #include <math.h>
@@ -25,105 +26,131 @@ struct PtWide4 {
 };
 static_assert(sizeof(PtWide4) == 64, "wide node must be 64 bytes");
 
-static inline float pt_grid_scale(uint32_t exp_byte)
+#if defined(__HIPCC__)
+#define PT_HD __host__ __device__
+#else
+#define PT_HD
+#endif
+#define PT_WIDE_EMPTY ((int32_t)0x80000000)
+
+struct PtWideEntry { int32_t ref; float lo[3], hi[3]; };
+
+PT_HD static inline float pt_grid_scale(uint32_t exp_byte)
 {
-    uint32_t bits = exp_byte << 23; float scale; memcpy(&scale, &bits, 4);
-    return scale;
+    union { uint32_t u; float f; } c;
+    c.u = exp_byte << 23;
+    return c.f;
 }
-static inline float pt_grid_plane(uint32_t q, float scale, float origin)
+PT_HD static inline float pt_grid_plane(uint32_t q, float scale, float origin)
 {
     return __builtin_fmaf((float)q, scale, origin);
 }
 
-// Collapses one binary BVH (host copy) into wide nodes appended to `out`.  Inner references are
-// rebased by the position of the first appended node, leaf references by tri_base.  Returns the
-// depth of the wide tree (a single node has depth 1).
+// Entries of the wide node that stands for binary node `node`: its children, then, while fewer
+// than four entries exist, the inner entry with the largest surface area is replaced by its own
+// children.  Returns the number of entries (1..4).
+PT_HD static inline int pt_wide_open(const PtBvhNode* n2, uint32_t node, PtWideEntry ent[4])
+{
+    int ne = 0;
+#define PT_WIDE_ADD(c, lo_, hi_) { ent[ne].ref = (c); for (int k_ = 0; k_ < 3; ++k_) { ent[ne].lo[k_] = (lo_)[k_]; ent[ne].hi[k_] = (hi_)[k_]; } ++ne; }
+    const PtBvhNode& nd = n2[node];
+    if (nd.c0 != PT_WIDE_EMPTY) PT_WIDE_ADD(nd.c0, nd.lo0, nd.hi0)
+    if (nd.c1 != PT_WIDE_EMPTY) PT_WIDE_ADD(nd.c1, nd.lo1, nd.hi1)
+    while (ne < 4) {
+        int pick = -1; float pick_area = -1.0f;
+        for (int e = 0; e < ne; ++e) {
+            if (ent[e].ref < 0) continue;
+            const float dx = ent[e].hi[0] - ent[e].lo[0], dy = ent[e].hi[1] - ent[e].lo[1], dz = ent[e].hi[2] - ent[e].lo[2];
+            const float area = dx * dy + dy * dz + dz * dx;
+            if (area > pick_area) { pick_area = area; pick = e; }
+        }
+        if (pick < 0) break;
+        const PtBvhNode& ch = n2[ent[pick].ref];
+        ent[pick] = ent[--ne];
+        if (ch.c0 != PT_WIDE_EMPTY) PT_WIDE_ADD(ch.c0, ch.lo0, ch.hi0)
+        if (ch.c1 != PT_WIDE_EMPTY) PT_WIDE_ADD(ch.c1, ch.lo1, ch.hi1)
+    }
+#undef PT_WIDE_ADD
+    return ne;
+}
+
+// Fills origin, grid steps and quantised planes of `w` (zeroed by the caller) from the entries;
+// child references are left to the caller.  Every dequantised box contains its entry's box.
+PT_HD static inline void pt_wide_quantise(const PtWideEntry* ent, int ne, PtWide4& w)
+{
+    float lo[3], hi[3];
+    for (int k = 0; k < 3; ++k) { lo[k] = ent[0].lo[k]; hi[k] = ent[0].hi[k]; }
+    for (int e = 1; e < ne; ++e) for (int k = 0; k < 3; ++k) { lo[k] = fminf(lo[k], ent[e].lo[k]); hi[k] = fmaxf(hi[k], ent[e].hi[k]); }
+    float scales[3];
+    for (int k = 0; k < 3; ++k) {
+        w.origin[k] = lo[k];
+        // smallest power-of-two step with 255 steps covering the extent; grown until every plane fits
+        int e2; const float ext = hi[k] - lo[k];
+        if (!(ext > 0.0f)) e2 = -126; else { (void)frexpf(ext / 255.0f, &e2); }
+        int eb = e2 + 127; if (eb < 1) eb = 1; if (eb > 254) eb = 254;
+        for (;; ++eb) {
+            const float scale = pt_grid_scale((uint32_t)eb);
+            bool ok = true;
+            for (int e = 0; e < ne && ok; ++e) {
+                const double qh = ceil(((double)ent[e].hi[k] - (double)lo[k]) / (double)scale);
+                if (qh > 255.0) ok = false;
+                else { uint32_t q = (uint32_t)(qh < 0 ? 0 : qh); while (q <= 255 && pt_grid_plane(q, scale, lo[k]) < ent[e].hi[k]) ++q; if (q > 255) ok = false; }
+            }
+            if (ok || eb >= 254) break;
+        }
+        scales[k] = pt_grid_scale((uint32_t)eb);
+    }
+    w.scale_x = scales[0]; w.scale_y = scales[1]; w.scale_z = scales[2];
+    for (int e = 0; e < ne; ++e) {
+        for (int k = 0; k < 3; ++k) {
+            const float scale = scales[k];
+            const double ql = floor(((double)ent[e].lo[k] - (double)lo[k]) / (double)scale);
+            uint32_t q_lo = (uint32_t)(ql < 0 ? 0 : (ql > 255 ? 255 : ql));
+            while (q_lo > 0 && pt_grid_plane(q_lo, scale, lo[k]) > ent[e].lo[k]) --q_lo;
+            const double qh = ceil(((double)ent[e].hi[k] - (double)lo[k]) / (double)scale);
+            uint32_t q_hi = (uint32_t)(qh < 0 ? 0 : (qh > 255 ? 255 : qh));
+            while (q_hi < 255 && pt_grid_plane(q_hi, scale, lo[k]) < ent[e].hi[k]) ++q_hi;
+            w.q[k] |= q_lo << (8 * e);
+            w.q[3 + k] |= q_hi << (8 * e);
+        }
+    }
+}
+
+// Leaf reference with its triangle position moved by tri_base.
+PT_HD static inline int32_t pt_wide_leaf_rebased(int32_t ref, uint32_t tri_base)
+{
+    const uint32_t code = ~(uint32_t)ref;
+    return (int32_t)~((((code >> 3) + tri_base) << 3) | (code & 7u));
+}
+
+// Host collapse of one binary BVH into wide nodes appended to `out`, breadth first: the wide node
+// of a binary node is numbered when its parent wide node is written, level by level, which is the
+// numbering the GPU builder reproduces with a scan per level.  Inner references are rebased by the
+// position of the first appended node, leaf references by tri_base.  Returns the depth of the wide
+// tree (a single node has depth 1).
 static inline uint32_t pt_collapse_to_wide(const std::vector<PtBvhNode>& n2, uint32_t tri_base, std::vector<PtWide4>& out)
 {
-    const int32_t EMPTY = std::numeric_limits<int32_t>::min();
     const uint32_t base = (uint32_t)out.size();
     std::vector<uint32_t> todo { 0 };            // binary nodes that become wide nodes, in breadth-first order
-    std::vector<int32_t> wide_of(n2.size(), -1);
     std::vector<uint32_t> depth_of { 1 };
     uint32_t max_depth = 1;
-    wide_of[0] = 0;
     for (size_t head = 0; head < todo.size(); ++head) {
-        const PtBvhNode& nd = n2[todo[head]];
-        struct Entry { int32_t ref; float lo[3], hi[3]; };
-        Entry ent[4]; int ne = 0;
-        auto add = [&](int32_t ref, const float* lo, const float* hi) { ent[ne].ref = ref; for (int k = 0; k < 3; ++k) { ent[ne].lo[k] = lo[k]; ent[ne].hi[k] = hi[k]; } ++ne; };
-        if (nd.c0 != EMPTY) add(nd.c0, nd.lo0, nd.hi0);
-        if (nd.c1 != EMPTY) add(nd.c1, nd.lo1, nd.hi1);
-        // open the inner entry with the largest surface area until the node is full
-#ifndef PT_WIDE_GREEDY
-#define PT_WIDE_GREEDY 1
-#endif
-        while (PT_WIDE_GREEDY ? ne < 4 : false) {
-            int pick = -1; float pick_area = -1.0f;
-            for (int e = 0; e < ne; ++e) {
-                if (ent[e].ref < 0) continue;
-                const float dx = ent[e].hi[0] - ent[e].lo[0], dy = ent[e].hi[1] - ent[e].lo[1], dz = ent[e].hi[2] - ent[e].lo[2];
-                const float area = dx * dy + dy * dz + dz * dx;
-                if (area > pick_area) { pick_area = area; pick = e; }
-            }
-            if (pick < 0) break;
-            const PtBvhNode& ch = n2[ent[pick].ref];
-            ent[pick] = ent[--ne];
-            if (ch.c0 != EMPTY) add(ch.c0, ch.lo0, ch.hi0);
-            if (ch.c1 != EMPTY) add(ch.c1, ch.lo1, ch.hi1);
-        }
+        PtWideEntry ent[4];
+        const int ne = pt_wide_open(n2.data(), todo[head], ent);
         PtWide4 w; memset(&w, 0, sizeof w);
-        float lo[3], hi[3];
-        for (int k = 0; k < 3; ++k) { lo[k] = ent[0].lo[k]; hi[k] = ent[0].hi[k]; }
-        for (int e = 1; e < ne; ++e) for (int k = 0; k < 3; ++k) { lo[k] = fminf(lo[k], ent[e].lo[k]); hi[k] = fmaxf(hi[k], ent[e].hi[k]); }
-        uint32_t ex[3];
-        for (int k = 0; k < 3; ++k) {
-            w.origin[k] = lo[k];
-            // smallest power-of-two step with 255 steps covering the extent; grown until every plane fits
-            int e2; float ext = hi[k] - lo[k];
-            if (!(ext > 0.0f)) e2 = -126; else { (void)frexpf(ext / 255.0f, &e2); }
-            int eb = e2 + 127; if (eb < 1) eb = 1; if (eb > 254) eb = 254;
-            for (;; ++eb) {
-                bool ok = true;
-                for (int e = 0; e < ne && ok; ++e) {
-                    uint32_t bits = (uint32_t)eb << 23; float scale; memcpy(&scale, &bits, 4);
-                    double qh = ceil(((double)ent[e].hi[k] - (double)lo[k]) / (double)scale);
-                    if (qh > 255.0) ok = false;
-                    else { uint32_t q = (uint32_t)(qh < 0 ? 0 : qh); while (q <= 255 && pt_grid_plane(q, scale, lo[k]) < ent[e].hi[k]) ++q; if (q > 255) ok = false; }
-                }
-                if (ok || eb >= 254) break;
-            }
-            ex[k] = (uint32_t)eb;
-        }
-        w.scale_x = pt_grid_scale(ex[0]); w.scale_y = pt_grid_scale(ex[1]); w.scale_z = pt_grid_scale(ex[2]);
-        for (int e = 0; e < 4; ++e) w.child[e] = EMPTY;
+        pt_wide_quantise(ent, ne, w);
+        for (int e = 0; e < 4; ++e) w.child[e] = PT_WIDE_EMPTY;
         for (int e = 0; e < ne; ++e) {
-            for (int k = 0; k < 3; ++k) {
-                uint32_t bits = ex[k] << 23; float scale; memcpy(&scale, &bits, 4);
-                double ql = floor(((double)ent[e].lo[k] - (double)lo[k]) / (double)scale);
-                uint32_t q_lo = (uint32_t)(ql < 0 ? 0 : (ql > 255 ? 255 : ql));
-                while (q_lo > 0 && pt_grid_plane(q_lo, scale, lo[k]) > ent[e].lo[k]) --q_lo;
-                double qh = ceil(((double)ent[e].hi[k] - (double)lo[k]) / (double)scale);
-                uint32_t q_hi = (uint32_t)(qh < 0 ? 0 : (qh > 255 ? 255 : qh));
-                while (q_hi < 255 && pt_grid_plane(q_hi, scale, lo[k]) < ent[e].hi[k]) ++q_hi;
-                w.q[k] |= q_lo << (8 * e);
-                w.q[3 + k] |= q_hi << (8 * e);
-            }
-            int32_t ref = ent[e].ref;
-            if (ref >= 0) {
-                if (wide_of[ref] < 0) {
-                    wide_of[ref] = (int32_t)todo.size(); todo.push_back((uint32_t)ref);
-                    depth_of.push_back(depth_of[head] + 1);
-                    max_depth = depth_of[head] + 1 > max_depth ? depth_of[head] + 1 : max_depth;
-                }
-                w.child[e] = (int32_t)(base + (uint32_t)wide_of[ref]);
+            if (ent[e].ref >= 0) {
+                w.child[e] = (int32_t)(base + (uint32_t)todo.size());
+                todo.push_back((uint32_t)ent[e].ref);
+                depth_of.push_back(depth_of[head] + 1);
+                max_depth = depth_of[head] + 1 > max_depth ? depth_of[head] + 1 : max_depth;
             } else {
-                uint32_t code = ~(uint32_t)ref;
-                w.child[e] = (int32_t)~((((code >> 3) + tri_base) << 3) | (code & 7u));
+                w.child[e] = pt_wide_leaf_rebased(ent[e].ref, tri_base);
             }
         }
         out.push_back(w);
     }
     return max_depth;
 }
-
