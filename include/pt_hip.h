@@ -143,6 +143,14 @@ int pt_blas_info(const PtBlas* blas, PtAsInfo* out);
 /* Copies the built structure to the host (any pointer may be NULL): nodes[node_count],
  * leaf_prims[prim_count] (primitive ids in sorted order), sorted_keys[prim_count]. */
 int pt_blas_download(const PtBlas* blas, PtBvhNode* nodes, uint32_t* leaf_prims, uint64_t* sorted_keys);
+/* The layout the kernels traverse, derived on the GPU from the binary nodes above: 64-byte nodes
+ * with four children whose boxes are quantised to 8 bits on a per-node power-of-two grid
+ * { float origin[3]; float step_x; int32 child[4]; uint32 q[6] (lo.x lo.y lo.z hi.x hi.y hi.z, byte k
+ * = child k); float step_y, step_z }, numbered breadth first, references local to the structure.
+ * nodes64 may be NULL to query the count and depth only.  A driver keeps its traversal format
+ * private (the reference only sees buffer sizes, bottom_level_...cpp:95-110); it is exposed here
+ * so that it can be checked. */
+int pt_blas_wide_download(const PtBlas* blas, void* nodes64, uint32_t capacity, uint32_t* count_out, uint32_t* depth_out);
 
 /* Replaces the TLAS build of source/top_level_acceleration_structure.cpp:19-113: n instance
  * records in host memory.  Blocks until built. */
@@ -151,6 +159,7 @@ int pt_tlas_destroy(PtTlas* tlas);   /* top_level_...cpp:16 */
 int pt_tlas_info(const PtTlas* tlas, PtAsInfo* out);
 int pt_tlas_download(const PtTlas* tlas, PtBvhNode* nodes, uint32_t* leaf_instances,
                      float* instance_boxes /* n x 6 */, float* instance_w2o /* n x 12 */);
+int pt_tlas_wide_download(const PtTlas* tlas, void* nodes64, uint32_t capacity, uint32_t* count_out, uint32_t* depth_out);
 
 /* Replaces BindlessResources::UpdateDescriptorSet (source/resources/bindless_resources.cpp:70-76,
  * bindings 0-3 of set 0, :250-274): copies the four tables to the GPU.  Table sizes are capped at

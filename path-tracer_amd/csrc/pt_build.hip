@@ -361,6 +361,60 @@ __global__ void k_pack_tris(const uint8_t* __restrict__ vertices, uint32_t strid
     tris[3 * (size_t)i + 2] = make_float4(c[2], __uint_as_float(p), 0.0f, 0.0f);
 }
 
+// ---- traversal layout on the device: one breadth-first level per pass (pt_wide.h has the per-node routines)
+__global__ void k_wide_count(const PtBvhNode* __restrict__ n2, const uint32_t* __restrict__ frontier, uint32_t n_front,
+                             uint32_t* __restrict__ counts)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_front) return;
+    PtWideEntry ent[4];
+    const int ne = pt_wide_open(n2, frontier[i], ent);
+    uint32_t c = 0;
+    for (int e = 0; e < ne; ++e) c += ent[e].ref >= 0 ? 1u : 0u;
+    counts[i] = c;
+}
+
+// Wide node level_base + i stands for frontier[i]; its inner entries become the next level in
+// frontier order (offsets = exclusive scan of the counts), which is the numbering of a host
+// breadth-first walk.
+__global__ void k_wide_emit(const PtBvhNode* __restrict__ n2, const uint32_t* __restrict__ frontier, uint32_t n_front,
+                            const uint32_t* __restrict__ offsets, uint32_t level_base, PtWide4* __restrict__ out,
+                            uint32_t* __restrict__ next_frontier)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_front) return;
+    PtWideEntry ent[4];
+    const int ne = pt_wide_open(n2, frontier[i], ent);
+    PtWide4 w;
+    w.origin[0] = w.origin[1] = w.origin[2] = 0.0f; w.scale_x = w.scale_y = w.scale_z = 0.0f;
+    for (int k = 0; k < 6; ++k) w.q[k] = 0u;
+    pt_wide_quantise(ent, ne, w);
+    uint32_t k = offsets[i];
+    for (int e = 0; e < 4; ++e) {
+        if (e >= ne) { w.child[e] = PT_WIDE_EMPTY; continue; }
+        if (ent[e].ref >= 0) {
+            w.child[e] = (int32_t)(level_base + n_front + k);
+            next_frontier[k] = (uint32_t)ent[e].ref;
+            ++k;
+        } else w.child[e] = ent[e].ref;
+    }
+    out[level_base + i] = w;
+}
+
+// Copies wide nodes into a pool: inner references move by node_base, triangle positions by tri_base.
+__global__ void k_wide_rebase(const PtWide4* __restrict__ in, uint32_t n, uint32_t node_base, uint32_t tri_base, PtWide4* __restrict__ out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    PtWide4 w = in[i];
+    for (int e = 0; e < 4; ++e) {
+        const int32_t c = w.child[e];
+        if (c == PT_WIDE_EMPTY) continue;
+        w.child[e] = c >= 0 ? (int32_t)((uint32_t)c + node_base) : pt_wide_leaf_rebased(c, tri_base);
+    }
+    out[node_base + i] = w;
+}
+
 inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
 struct DevMem {   // frees everything it allocated when it goes out of scope
@@ -410,6 +464,38 @@ int radix_sort_pairs(hipStream_t st, DevMem& mem, uint64_t** keys, uint32_t** va
 }
 
 } // namespace
+
+int pt_build_wide(PtContext* ctx, const PtBvhNode* nodes_dev, uint32_t node_count, void** wide_out, uint32_t* count_out, uint32_t* depth_out)
+{
+    hipStream_t st = ctx->stream;
+    DevMem mem;
+    uint32_t *front_a = nullptr, *front_b = nullptr, *counts = nullptr, *offsets = nullptr, *total = nullptr;
+    PtWide4* wide = nullptr;
+    // every wide node stands for a distinct binary node
+    PT_HIP_CHECK(mem.alloc(&front_a, node_count)); PT_HIP_CHECK(mem.alloc(&front_b, node_count));
+    PT_HIP_CHECK(mem.alloc(&counts, node_count)); PT_HIP_CHECK(mem.alloc(&offsets, node_count)); PT_HIP_CHECK(mem.alloc(&total, 4));
+    PT_HIP_CHECK(hipMalloc((void**)&wide, sizeof(PtWide4) * (size_t)node_count));
+    auto fail = [&](int code) { (void)hipFree(wide); return code; };
+    if (hipMemsetAsync(front_a, 0, 4, st) != hipSuccess) return fail(PT_ERROR_HIP);   // the root
+    uint32_t n_front = 1, level_base = 0, depth = 0;
+    while (n_front) {
+        ++depth;
+        if (level_base + n_front > node_count || depth > 4096) { pt_set_error("pt_build_wide: the binary tree is not a tree"); return fail(PT_ERROR_HIP); }
+        const uint32_t nb = div_up(n_front, kBlock);
+        k_wide_count<<<nb, kBlock, 0, st>>>(nodes_dev, front_a, n_front, counts);
+        int rc = scan_exclusive(st, mem, counts, offsets, n_front, total);
+        if (rc) return fail(rc);
+        k_wide_emit<<<nb, kBlock, 0, st>>>(nodes_dev, front_a, n_front, offsets, level_base, wide, front_b);
+        uint32_t next = 0;
+        if (hipMemcpyAsync(&next, total, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+            pt_set_error("pt_build_wide: %s", hipGetErrorString(hipGetLastError())); return fail(PT_ERROR_HIP);
+        }
+        level_base += n_front; n_front = next;
+        std::swap(front_a, front_b);
+    }
+    *wide_out = wide; *count_out = level_base; *depth_out = depth;
+    return PT_OK;
+}
 
 int pt_build_lbvh(PtContext* ctx, const float* boxes, uint32_t n, uint32_t max_leaf,
                   PtBvhNode** nodes_out, uint32_t* node_count_out, uint32_t** leaf_prims_out, uint64_t** sorted_keys_out)
@@ -528,6 +614,8 @@ int pt_blas_build(PtContext* ctx, const void* vertices_dev, uint32_t vertex_stri
     b->indices = indices_dev; b->prim_count = prim_count; b->max_leaf = max_leaf;
     int rc = pt_build_lbvh(ctx, boxes, prim_count, max_leaf, &b->nodes, &b->node_count, &b->leaf_prims, &b->sorted_keys);
     if (rc) { delete b; return rc; }
+    rc = pt_build_wide(ctx, b->nodes, b->node_count, &b->wide, &b->wide_count, &b->wide_depth);
+    if (rc) { pt_blas_destroy(b); return rc; }
     uint32_t host_scal[7];
     hipError_t e = hipMalloc((void**)&b->tris, sizeof(float4) * 3 * (size_t)prim_count);
     if (e == hipSuccess) {
@@ -549,7 +637,7 @@ int pt_blas_build(PtContext* ctx, const void* vertices_dev, uint32_t vertex_stri
 int pt_blas_destroy(PtBlas* b)
 {
     if (!b) return PT_OK;
-    (void)hipFree(b->nodes); (void)hipFree(b->tris); (void)hipFree(b->leaf_prims); (void)hipFree(b->sorted_keys);
+    (void)hipFree(b->nodes); (void)hipFree(b->tris); (void)hipFree(b->leaf_prims); (void)hipFree(b->sorted_keys); (void)hipFree(b->wide);
     delete b;
     return PT_OK;
 }
@@ -560,6 +648,30 @@ int pt_blas_info(const PtBlas* b, PtAsInfo* out)
     out->node_count = b->node_count; out->prim_count = b->prim_count;
     for (int k = 0; k < 3; ++k) { out->root_lo[k] = b->root_lo[k]; out->root_hi[k] = b->root_hi[k]; }
     out->delta = b->delta; out->build_ms = b->build_ms;
+    return PT_OK;
+}
+
+int pt_blas_wide_download(const PtBlas* b, void* nodes64, uint32_t capacity, uint32_t* count_out, uint32_t* depth_out)
+{
+    PT_REQUIRE(b, "null argument");
+    if (count_out) *count_out = b->wide_count;
+    if (depth_out) *depth_out = b->wide_depth;
+    if (!nodes64) return PT_OK;
+    PT_REQUIRE(capacity >= b->wide_count, "capacity is smaller than the number of wide nodes");
+    PT_HIP_CHECK(hipSetDevice(b->ctx->device));
+    PT_HIP_CHECK(hipMemcpy(nodes64, b->wide, sizeof(PtWide4) * (size_t)b->wide_count, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+int pt_tlas_wide_download(const PtTlas* t, void* nodes64, uint32_t capacity, uint32_t* count_out, uint32_t* depth_out)
+{
+    PT_REQUIRE(t, "null argument");
+    if (count_out) *count_out = t->wide_count;
+    if (depth_out) *depth_out = t->wide_depth;
+    if (!nodes64) return PT_OK;
+    PT_REQUIRE(capacity >= t->wide_count, "capacity is smaller than the number of wide nodes");
+    PT_HIP_CHECK(hipSetDevice(t->ctx->device));
+    PT_HIP_CHECK(hipMemcpy(nodes64, t->pool_nodes, sizeof(PtWide4) * (size_t)t->wide_count, hipMemcpyDeviceToHost));
     return PT_OK;
 }
 
@@ -672,32 +784,35 @@ int pt_tlas_build(PtContext* ctx, const PtInstance* instances, uint32_t n, PtTla
             blas_of_inst[i] = (uint32_t)k;
         }
         if (nt >= (1u << 28)) { pt_set_error("pt_tlas_build: more than 2^28 triangles in one TLAS"); pt_tlas_destroy(t); return PT_ERROR_LIMIT; }
-        std::vector<PtWide4> wide;
-        std::vector<PtBvhNode> host2(t->node_count);
-        e = hipMemcpy(host2.data(), t->nodes, sizeof(PtBvhNode) * t->node_count, hipMemcpyDeviceToHost);
-        uint32_t depth_tlas = 0, depth_blas = 0;
-        if (e == hipSuccess) depth_tlas = pt_collapse_to_wide(host2, 0, wide);
+        void* tlas_wide = nullptr;
+        rc = pt_build_wide(ctx, t->nodes, t->node_count, &tlas_wide, &t->wide_count, &t->wide_depth);
+        if (rc) { pt_tlas_destroy(t); return rc; }
+        uint32_t total_nodes = t->wide_count, depth_blas = 0;
         std::vector<uint32_t> root_of(uniq.size());
-        for (size_t k = 0; k < uniq.size() && e == hipSuccess; ++k) {
-            host2.resize(uniq[k]->node_count);
-            e = hipMemcpy(host2.data(), uniq[k]->nodes, sizeof(PtBvhNode) * uniq[k]->node_count, hipMemcpyDeviceToHost);
-            root_of[k] = (uint32_t)wide.size();
-            if (e == hipSuccess) { const uint32_t d = pt_collapse_to_wide(host2, tri_base[k], wide); depth_blas = d > depth_blas ? d : depth_blas; }
+        for (size_t k = 0; k < uniq.size(); ++k) {
+            root_of[k] = total_nodes; total_nodes += uniq[k]->wide_count;
+            depth_blas = uniq[k]->wide_depth > depth_blas ? uniq[k]->wide_depth : depth_blas;
         }
         // a step pushes at most three references and an instance entry one
-        if (e == hipSuccess && 3 * depth_tlas + 1 + 3 * depth_blas > PT_LDS_STACK + PT_SPILL_STACK) {
-            pt_set_error("pt_tlas_build: acceleration structure too deep for the traversal stack (%u + %u wide levels)", depth_tlas, depth_blas);
-            pt_tlas_destroy(t); return PT_ERROR_LIMIT;
+        if (3 * t->wide_depth + 1 + 3 * depth_blas > PT_LDS_STACK + PT_SPILL_STACK) {
+            pt_set_error("pt_tlas_build: acceleration structure too deep for the traversal stack (%u + %u wide levels)", t->wide_depth, depth_blas);
+            (void)hipFree(tlas_wide); pt_tlas_destroy(t); return PT_ERROR_LIMIT;
         }
         for (uint32_t i = 0; i < n; ++i) { float rootf; memcpy(&rootf, &root_of[blas_of_inst[i]], 4); di[i].q[5].x = rootf; }
-        if (e == hipSuccess) e = hipMalloc((void**)&t->pool_nodes, sizeof(PtWide4) * wide.size());
+        e = hipMalloc((void**)&t->pool_nodes, sizeof(PtWide4) * (size_t)total_nodes);
         if (e == hipSuccess) e = hipMalloc((void**)&t->pool_tris, sizeof(float4) * 3 * (size_t)(nt ? nt : 1));
-        if (e == hipSuccess) e = hipMemcpyAsync(t->pool_nodes, wide.data(), sizeof(PtWide4) * wide.size(), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) {
+            k_wide_rebase<<<div_up(t->wide_count, kBlock), kBlock, 0, st>>>((const PtWide4*)tlas_wide, t->wide_count, 0, 0, (PtWide4*)t->pool_nodes);
+            for (size_t k = 0; k < uniq.size(); ++k)
+                k_wide_rebase<<<div_up(uniq[k]->wide_count, kBlock), kBlock, 0, st>>>((const PtWide4*)uniq[k]->wide, uniq[k]->wide_count, root_of[k], tri_base[k], (PtWide4*)t->pool_nodes);
+            e = hipGetLastError();
+        }
         for (size_t k = 0; k < uniq.size() && e == hipSuccess; ++k)
             e = hipMemcpyAsync(t->pool_tris + 3 * (size_t)tri_base[k], uniq[k]->tris, sizeof(float4) * 3 * (size_t)uniq[k]->prim_count, hipMemcpyDeviceToDevice, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);   // `wide` is host memory that goes out of scope
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        (void)hipFree(tlas_wide);
         if (e != hipSuccess) { pt_set_error("pt_tlas_build: %s", hipGetErrorString(e)); pt_tlas_destroy(t); return PT_ERROR_HIP; }
-        t->pool_node_count = (uint32_t)wide.size();
+        t->pool_node_count = total_nodes;
     }
     e = hipMalloc((void**)&t->inst, sizeof(PtDevInstance) * n);
     if (e == hipSuccess) e = hipMalloc((void**)&t->shade_inst, sizeof(PtDevShadeInstance) * n);

@@ -55,6 +55,8 @@ struct PtBlas {
     float4* tris;            // device, 3 float4 per sorted slot
     uint32_t* leaf_prims;    // device, prim ids in sorted order
     uint64_t* sorted_keys;   // device
+    void* wide;              // device: 64-byte 4-wide quantised nodes of this BLAS, references local (root 0, triangle 0)
+    uint32_t wide_count, wide_depth;
     float build_ms;
 };
 
@@ -66,6 +68,7 @@ struct PtTlas {
     void* pool_nodes;               // device: 64-byte 4-wide quantised nodes, TLAS first then every distinct BLAS, references absolute
     float4* pool_tris;              // device: triangle records of every distinct BLAS, 3 float4 each
     uint32_t pool_node_count;
+    uint32_t wide_count, wide_depth;  // the TLAS's own wide nodes: the first wide_count of the pool
     uint32_t* leaf_inst;            // device, instance index per sorted slot
     PtDevInstance* inst;            // device, n
     PtDevShadeInstance* shade_inst; // device, n; rebuilt when the context's tables change
@@ -142,5 +145,6 @@ int pt_lanes_join(PtContext* ctx);                          // the caller's stre
 int pt_lanes_sync(PtContext* ctx);                          // the host waits for every lane and the caller's stream
 
 // pt_build.hip
+int pt_build_wide(PtContext* ctx, const PtBvhNode* nodes_dev, uint32_t node_count, void** wide_out, uint32_t* count_out, uint32_t* depth_out);
 int pt_build_lbvh(PtContext* ctx, const float* prim_boxes_dev /* n x 6: lo, hi */, uint32_t n, uint32_t max_leaf,
                   PtBvhNode** nodes_out, uint32_t* node_count_out, uint32_t** leaf_prims_out, uint64_t** sorted_keys_out);

@@ -40,6 +40,9 @@ INSTANCE = np.dtype([
 
 TEXTURE_DESC = np.dtype([("rgba8", "<u8"), ("width", "<u4"), ("height", "<u4")])
 
+# 64-byte 4-wide node of the traversal layout (pt_blas_wide_download)
+WIDE_NODE = np.dtype([("origin", "<f4", 3), ("scale_x", "<f4"), ("child", "<i4", 4), ("q", "<u4", 6), ("scale_y", "<f4"), ("scale_z", "<f4")])
+
 BVH_NODE = np.dtype([
     ("lo0", "<f4", 3), ("hi0", "<f4", 3), ("lo1", "<f4", 3), ("hi1", "<f4", 3),
     ("c0", "<i4"), ("c1", "<i4"), ("aux0", "<u4"), ("aux1", "<u4"),

@@ -41,6 +41,8 @@ SIGNATURES = {
     "pt_blas_destroy": (_i, [_vp]),
     "pt_blas_info": (_i, [_vp, _vp]),
     "pt_blas_download": (_i, [_vp, _vp, _vp, _vp]),
+    "pt_blas_wide_download": (_i, [_vp, _vp, _u32, _vp, _vp]),
+    "pt_tlas_wide_download": (_i, [_vp, _vp, _u32, _vp, _vp]),
     "pt_tlas_build": (_i, [_vp, _vp, _u32, C.POINTER(_vp)]),
     "pt_tlas_destroy": (_i, [_vp]),
     "pt_tlas_info": (_i, [_vp, _vp]),
@@ -173,6 +175,14 @@ class BottomLevelAccelerationStructure:
         _check(self.ctx.lib.pt_blas_download(self.h, _p(nodes), _p(prims), _p(keys)))
         return nodes, prims, keys
 
+    def download_wide(self):
+        """(wide nodes, depth) of the traversal layout."""
+        cnt, depth = C.c_uint32(0), C.c_uint32(0)
+        _check(self.ctx.lib.pt_blas_wide_download(self.h, None, 0, C.byref(cnt), C.byref(depth)))
+        nodes = np.zeros(cnt.value, dtype=abi.WIDE_NODE)
+        _check(self.ctx.lib.pt_blas_wide_download(self.h, _p(nodes), cnt.value, None, None))
+        return nodes, depth.value
+
     def destroy(self):
         if self.h:
             self.ctx.lib.pt_blas_destroy(self.h)
@@ -207,6 +217,14 @@ class TopLevelAccelerationStructure:
         w2o = np.zeros((self.n, 12), dtype=np.float32)
         _check(self.ctx.lib.pt_tlas_download(self.h, _p(nodes), _p(leaf), _p(boxes), _p(w2o)))
         return nodes, leaf, boxes, w2o
+
+    def download_wide(self):
+        """(wide nodes, depth) of the traversal layout."""
+        cnt, depth = C.c_uint32(0), C.c_uint32(0)
+        _check(self.ctx.lib.pt_tlas_wide_download(self.h, None, 0, C.byref(cnt), C.byref(depth)))
+        nodes = np.zeros(cnt.value, dtype=abi.WIDE_NODE)
+        _check(self.ctx.lib.pt_tlas_wide_download(self.h, _p(nodes), cnt.value, None, None))
+        return nodes, depth.value
 
     def destroy(self):
         if self.h:

@@ -17,7 +17,7 @@ from pt_amd import abi
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(ROOT, "path-tracer_amd", "lib", "libpt_wide_host.so")
 
-WIDE4 = np.dtype([("origin", "<f4", 3), ("scale_x", "<f4"), ("child", "<i4", 4), ("q", "<u4", 6), ("scale_y", "<f4"), ("scale_z", "<f4")])
+WIDE4 = abi.WIDE_NODE
 EMPTY = -2**31
 
 
@@ -174,3 +174,25 @@ def test_rays_reach_the_triangle_they_hit(name, n, request, wide_lib):
             reach.update(leaf_prims[first:first + cnt].tolist())
         assert int(hits["primitive"][i]) in reach
     assert n_hit > n // 20
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["cornell", "soup", "dragon"])
+def test_gpu_builder_matches_host_collapse(name, request, wide_lib):
+    """The GPU derives the wide nodes level by level with a scan; the host helper walks the same
+    binary nodes breadth first.  Same per-node routine, same numbering: the bytes must agree."""
+    from pt_amd import hip
+    scene = request.getfixturevalue(name)
+    r = hip.Renderer(scene, 32, 32)
+    try:
+        for b in r.blases:
+            nodes, _, _ = b.download()
+            got, depth = b.download_wide()
+            want, want_depth = collapse(wide_lib, nodes)
+            assert depth == want_depth and got.tobytes() == want.tobytes()
+        nodes = r.tlas.download()[0]
+        got, depth = r.tlas.download_wide()
+        want, want_depth = collapse(wide_lib, nodes)
+        assert depth == want_depth and got.tobytes() == want.tobytes()
+    finally:
+        r.close()
