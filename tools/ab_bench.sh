@@ -4,7 +4,7 @@ for spec in "$@"; do
   label=${spec%%=*}; rest=${spec#*=}
   lib=${rest%%,*}; envs=""
   if [[ "$rest" == *,* ]]; then envs=${rest#*,}; envs=${envs//,/ }; fi
-  out=$(env PT_HIP_LIB=$lib $envs timeout -k 10 200 python bench.py --steps 6 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1)
+  out=$(env PT_HIP_LIB=$lib $envs timeout -k 10 200 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --secondary 2>/dev/null | tail -1)
   python3 - "$label" "$out" <<'PY'
 import json,sys
 j=json.loads(sys.argv[2])

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Bench line summary for combinations of frames in flight and samples per step: tools/lanes_bench.sh "<lanes...>" "<spp...>"
 for spp in $2; do for l in $1; do
-  out=$(PT_HIP_FRAMES_IN_FLIGHT=$l timeout -k 10 200 python bench.py --steps $((128 / spp > 4 ? 128 / spp : 4)) --warmup 2 --no-cpu-baseline --no-secondary --spp $spp 2>/dev/null | tail -1)
+  out=$(timeout -k 10 200 python bench.py --frames-in-flight $l --steps $((128 / spp > 4 ? 128 / spp : 4)) --warmup 2 --no-cpu-baseline --no-secondary --spp $spp 2>/dev/null | tail -1)
   python3 - "$l" "$spp" "$out" <<'PY'
 import json,sys
 j=json.loads(sys.argv[3])
