@@ -100,11 +100,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal of the multi-rank path on a box with one GPU: every rank on device 0, gloo instead of RCCL
+    rehearsal = os.environ.get("PT_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     W, H = args.width, args.height
     scene = build_scene(args.scene)
