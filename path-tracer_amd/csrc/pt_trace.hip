@@ -123,17 +123,34 @@ k_generate(uint32_t n_paths, uint32_t pixel0, uint32_t spp, uint32_t W, uint32_t
 }
 
 // ------------------------------------------------------------------------------------------------
+// traceRayEXT for every ray of one bounce.  Two schedules share the kernel and the per-lane arithmetic:
+//   plain      a wave takes 64 rays and keeps them to the end.  Best for coherent primary rays and
+//              for levels with few rays per wave (deep bounces), where replacement has nothing to
+//              draw from and its bookkeeping only costs;
+//   scheduled  ray replacement and phase voting (pt_traverse_sched.h).  Best for the large
+//              incoherent levels in between (bounce 1-3 of the dragon frame: 25-30 % faster).
+// The level's size lives on the device, so the kernel decides: scheduled when the level holds at
+// least sched_min_rays rays (0 forces it, UINT32_MAX forces the plain schedule).
 // BY_ID: hit records go to hits[path id] (pt_intersect: caller's ray order) instead of the queue slot.
 template <bool BY_ID>
 __global__ void __launch_bounds__(kBlock, PT_INTERSECT_WAVES)
 k_intersect(PtTlasView tl, uint32_t* __restrict__ counters, uint32_t depth, uint32_t shard_cap,
             const float4* __restrict__ q0, const float4* __restrict__ q1, float tmin, float tmax,
-            PtHit* __restrict__ hits, float* __restrict__ t_out, int* __restrict__ spill)
+            PtHit* __restrict__ hits, float* __restrict__ t_out, int* __restrict__ spill, uint32_t sched_min_rays)
 {
     __shared__ int s_stack[PT_LDS_STACK][kBlock];
     PtStack stk;
     stk.lds = (pt_lds_int*)&s_stack[0][threadIdx.x];
     stk.spill_base = spill;
+    uint32_t total = counters[ctr_index(CTR_COUNT, depth, threadIdx.x & (kShards - 1))];   // lane s: shard s
+    for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off);
+    if (total >= sched_min_rays) {
+        PtSchedQueue Q;
+        Q.counters = counters; Q.shard_cap = shard_cap; Q.n_shards = kShards; Q.ctr_pad = kCtrPad;
+        Q.count_base = ctr_index(CTR_COUNT, depth, 0); Q.work_base = ctr_index(CTR_WORK_INTERSECT, depth, 0);
+        pt_traverse_sched<BY_ID>(tl, Q, stk, q0, q1, tmin, tmax, hits, t_out);
+        return;
+    }
     for_each_batch<false>(counters, CTR_WORK_INTERSECT, depth, shard_cap, [&](uint32_t i, bool valid, uint32_t) {
         if (valid) {
             const float4 o = q0[i], d = q1[i];
@@ -145,23 +162,6 @@ k_intersect(PtTlasView tl, uint32_t* __restrict__ counters, uint32_t depth, uint
             if (BY_ID && t_out) t_out[dst] = h.t;
         }
     });
-}
-
-// Same work, wave-scheduled: ray replacement + phase voting (pt_traverse_sched.h).
-template <bool BY_ID>
-__global__ void __launch_bounds__(kBlock, PT_INTERSECT_WAVES)
-k_intersect_sched(PtTlasView tl, uint32_t* __restrict__ counters, uint32_t depth, uint32_t shard_cap,
-                  const float4* __restrict__ q0, const float4* __restrict__ q1, float tmin, float tmax,
-                  PtHit* __restrict__ hits, float* __restrict__ t_out, int* __restrict__ spill)
-{
-    __shared__ int s_stack[PT_LDS_STACK][kBlock];
-    PtStack stk;
-    stk.lds = (pt_lds_int*)&s_stack[0][threadIdx.x];
-    stk.spill_base = spill;
-    PtSchedQueue Q;
-    Q.counters = counters; Q.shard_cap = shard_cap; Q.n_shards = kShards; Q.ctr_pad = kCtrPad;
-    Q.count_base = ctr_index(CTR_COUNT, depth, 0); Q.work_base = ctr_index(CTR_WORK_INTERSECT, depth, 0);
-    pt_traverse_sched<BY_ID>(tl, Q, stk, q0, q1, tmin, tmax, hits, t_out);
 }
 
 // rays given as packed float3 arrays (pt_intersect entry point): repack into the float4 streams
@@ -498,6 +498,14 @@ int ensure_shade_records(PtContext* ctx, const PtTlas* tlas_c)
     return PT_OK;
 }
 
+// Smallest level (in rays) the scheduled traversal is used for at bounce `depth`.
+uint32_t sched_threshold(const PtContext* ctx, uint32_t depth)
+{
+    if (ctx->traversal_mode == 0) return 0xFFFFFFFFu;        // plain everywhere
+    if (ctx->traversal_mode == 1) return 0u;                 // scheduled everywhere
+    return depth == 0 ? 0xFFFFFFFFu : ctx->sched_min_rays;   // primary rays are coherent
+}
+
 PtTlasView view_of(const PtTlas* t)
 {
     PtTlasView v;
@@ -524,14 +532,11 @@ int pt_intersect(PtContext* ctx, const PtTlas* tlas, uint32_t n, const float* or
     hipStream_t st = w.stream;
     PT_HIP_CHECK(hipMemsetAsync(w.counters, 0, sizeof(uint32_t) * kCounterWords, st));
     k_pack_rays<<<(n + kBlock - 1) / kBlock, kBlock, 0, st>>>(n, w.shard_cap, origins_dev, dirs_dev, w.q[0][0], w.q[0][1], w.counters);
-    if (ctx->traversal_mode == 0) {
-        int blocks = persistent_blocks(ctx, (const void*)k_intersect<true>);
+    {
+        // caller-supplied rays are treated as incoherent: scheduled above the threshold
+        const int blocks = persistent_blocks(ctx, (const void*)k_intersect<true>);
         k_intersect<true><<<blocks, kBlock, 0, st>>>(view_of(tlas), w.counters, 0, w.shard_cap, w.q[0][0], w.q[0][1],
-                                                     tmin, tmax, hits_dev, t_dev, w.spill);
-    } else {
-        int blocks = persistent_blocks(ctx, (const void*)k_intersect_sched<true>);
-        k_intersect_sched<true><<<blocks, kBlock, 0, st>>>(view_of(tlas), w.counters, 0, w.shard_cap, w.q[0][0], w.q[0][1],
-                                                           tmin, tmax, hits_dev, t_dev, w.spill);
+                                                     tmin, tmax, hits_dev, t_dev, w.spill, sched_threshold(ctx, 1));
     }
     PT_HIP_CHECK(hipGetLastError());
     return pt_lanes_join(ctx);   // the hit records are ordered on the caller's stream
@@ -558,8 +563,7 @@ int pt_trace(PtContext* ctx, const PtTlas* tlas, const float camera[32], uint32_
     const PtTlasView tv = view_of(tlas);
     PtCameraArg cam_arg;
     memcpy(cam_arg.m, camera, sizeof cam_arg.m);
-    const int blocks_i = ctx->traversal_mode == 0 ? persistent_blocks(ctx, (const void*)k_intersect<false>)
-                                                  : persistent_blocks(ctx, (const void*)k_intersect_sched<false>);
+    const int blocks_i = persistent_blocks(ctx, (const void*)k_intersect<false>);
     // Every chunk of the frame goes to the next lane and is left in flight there; only the
     // read-modify-write of the image is chained, in submission order.
     for (uint64_t p0 = 0; p0 < n_pixels; p0 += chunk_pixels) {
@@ -588,12 +592,8 @@ int pt_trace(PtContext* ctx, const PtTlas* tlas, const float camera[32], uint32_
                 ev_stop = ctx->ev_pool[ctx->ev_used + 1];
                 ctx->ev_used += 2;
             }
-            if (ctx->traversal_mode == 0)
-                k_intersect<false><<<blocks_i, kBlock, 0, st>>>(tv, w.counters, d, w.shard_cap, w.q[a][0], w.q[a][1],
-                                                                0.001f, 10000.0f, w.hits, nullptr, w.spill);
-            else
-                k_intersect_sched<false><<<blocks_i, kBlock, 0, st>>>(tv, w.counters, d, w.shard_cap, w.q[a][0], w.q[a][1],
-                                                                      0.001f, 10000.0f, w.hits, nullptr, w.spill);
+            k_intersect<false><<<blocks_i, kBlock, 0, st>>>(tv, w.counters, d, w.shard_cap, w.q[a][0], w.q[a][1],
+                                                            0.001f, 10000.0f, w.hits, nullptr, w.spill, sched_threshold(ctx, d));
             if (ev_stop) PT_HIP_CHECK(hipEventRecord(ev_stop, st));
 #define PT_SHADE_ARGS tlas->shade_inst, d, max_depth, w.counters, w.shard_cap, w.hits, w.q[a][0], w.q[a][1], w.q[a][2], w.q[a][3], \
                       w.q[b][0], w.q[b][1], w.q[b][2], w.q[b][3], w.path_result

@@ -20,6 +20,6 @@ n = launches["FETCH_SIZE"]
 assert n and n == launches["WRITE_SIZE"], launches
 fetch = tot["FETCH_SIZE"] * 1024.0 * 2.0
 write = tot["WRITE_SIZE"] * 1024.0
-print(json.dumps({"kernel": "k_intersect_sched", "launches": n, "fetch_bytes_per_launch": fetch / n, "write_bytes_per_launch": write / n,
+print(json.dumps({"kernel": "k_intersect", "launches": n, "fetch_bytes_per_launch": fetch / n, "write_bytes_per_launch": write / n,
                   "bytes_per_launch": (fetch + write) / n, "corrections": "FETCH_SIZE KiB x 1024 x 2 (gfx950), WRITE_SIZE KiB x 1024",
                   "command": "bench.py " + " ".join(sys.argv[2:])}))
