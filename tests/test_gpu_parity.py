@@ -64,8 +64,10 @@ def test_bvh_topology_bit_exact(name, request):
         r.close()
 
 
+@pytest.mark.parametrize("schedule", ["plain", "sched"])
 @pytest.mark.parametrize("name,n", [("cornell", 200000), ("cube", 100000), ("soup", 100000), ("dragon", 100000)])
-def test_intersect_hit_ids_bit_exact(name, n, request):
+def test_intersect_hit_ids_bit_exact(name, n, schedule, request, monkeypatch):
+    monkeypatch.setenv("PT_HIP_TRAVERSAL", schedule)   # both traversal schedules, whatever the level size
     scene = request.getfixturevalue(name)
     orc = _oracle(scene)
     r = _renderer(scene, 8, 8)
@@ -85,8 +87,10 @@ def test_intersect_hit_ids_bit_exact(name, n, request):
         r.close()
 
 
+@pytest.mark.parametrize("schedule", ["plain", "sched"])
 @pytest.mark.parametrize("name,w,h,spp", [("cornell", 128, 128, 16), ("cube", 96, 64, 8), ("dragon", 160, 90, 4), ("soup", 64, 64, 4)])
-def test_render_frame_bit_exact(name, w, h, spp, request):
+def test_render_frame_bit_exact(name, w, h, spp, schedule, request, monkeypatch):
+    monkeypatch.setenv("PT_HIP_TRAVERSAL", schedule)
     from pt_amd import camera
     scene = request.getfixturevalue(name)
     orc = _oracle(scene)
@@ -134,9 +138,11 @@ def test_exact_ties_between_instances(stacked, cornell):
         r.close()
 
 
-def test_cfg1_golden_full_size(cornell):
+@pytest.mark.parametrize("schedule", ["plain", "sched", "auto"])
+def test_cfg1_golden_full_size(cornell, schedule, monkeypatch):
     """BASELINE config 1 in full (Cornell 512x512, 16 spp, frame 0) against the committed oracle
     outputs: SHA-256 of the whole float image, the radiance crop, the ray count and the bounce-0 ids."""
+    monkeypatch.setenv("PT_HIP_TRAVERSAL", schedule)
     import hashlib
     import os
     from conftest import GOLDEN
