@@ -151,6 +151,12 @@ int pt_blas_download(const PtBlas* blas, PtBvhNode* nodes, uint32_t* leaf_prims,
  * private (the reference only sees buffer sizes, bottom_level_...cpp:95-110); it is exposed here
  * so that it can be checked. */
 int pt_blas_wide_download(const PtBlas* blas, void* nodes64, uint32_t capacity, uint32_t* count_out, uint32_t* depth_out);
+/* The binary tree the wide nodes are derived from, in the node format of pt_blas_download, and the
+ * primitive at each of its leaf positions.  By default this is a top-down binned-SAH tree built on the
+ * GPU next to the Morton tree (the reference asks its driver for ePreferFastTrace,
+ * bottom_level_...cpp:58); with PT_HIP_TRAVERSAL_TREE=lbvh it is the Morton tree itself.  The closest
+ * hit does not depend on the tree.  nodes may be NULL to query the count. */
+int pt_blas_traversal_download(const PtBlas* blas, PtBvhNode* nodes, uint32_t capacity, uint32_t* leaf_prims, uint32_t* count_out);
 
 /* Replaces the TLAS build of source/top_level_acceleration_structure.cpp:19-113: n instance
  * records in host memory.  Blocks until built. */

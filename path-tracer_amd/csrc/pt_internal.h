@@ -55,6 +55,9 @@ struct PtBlas {
     float4* tris;            // device, 3 float4 per sorted slot
     uint32_t* leaf_prims;    // device, prim ids in sorted order
     uint64_t* sorted_keys;   // device
+    PtBvhNode* trav_nodes;   // device: binned-SAH binary tree the traversal layout is derived from (null: the Morton tree is)
+    uint32_t trav_node_count;
+    uint32_t* trav_order;    // device: primitive at each leaf position of that tree (tris follow it)
     void* wide;              // device: 64-byte 4-wide quantised nodes of this BLAS, references local (root 0, triangle 0)
     uint32_t wide_count, wide_depth;
     float build_ms;

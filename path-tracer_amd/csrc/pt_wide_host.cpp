@@ -1,6 +1,7 @@
 // pt_wide_host.cpp -- C entry points over the host-side wide-node construction, for checking it
 // without a GPU: the collapse itself and a plain enumeration of the leaves a ray reaches.
 #include "pt_wide.h"
+#include "pt_sah.h"
 
 namespace {
 const float kDirEps = 8.271806125530277e-25f;   // 2^-80
@@ -20,6 +21,17 @@ uint32_t pt_wide_collapse_host(const PtBvhNode* nodes, uint32_t node_count, uint
     if (w.size() > cap) return 0;
     memcpy(out, w.data(), sizeof(PtWide4) * w.size());
     return (uint32_t)w.size();
+}
+
+// Host twin of the GPU binned-SAH builder: boxes n x 6, nodes_out capacity n, order_out n; returns the node count.
+uint32_t pt_sah_build_host_c(const float* boxes, uint32_t n, uint32_t max_leaf, const float* root_lo, const float* root_hi,
+                             PtBvhNode* nodes_out, uint32_t* order_out)
+{
+    std::vector<PtBvhNode> nodes; std::vector<uint32_t> ids;
+    pt_sah_build_host(boxes, n, max_leaf, root_lo, root_hi, nodes, ids);
+    memcpy(nodes_out, nodes.data(), sizeof(PtBvhNode) * nodes.size());
+    memcpy(order_out, ids.data(), sizeof(uint32_t) * n);
+    return (uint32_t)nodes.size();
 }
 
 // Writes the leaf codes (first << 3 | count - 1) of every leaf whose chain of dequantised boxes the

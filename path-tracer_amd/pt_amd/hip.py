@@ -42,6 +42,7 @@ SIGNATURES = {
     "pt_blas_info": (_i, [_vp, _vp]),
     "pt_blas_download": (_i, [_vp, _vp, _vp, _vp]),
     "pt_blas_wide_download": (_i, [_vp, _vp, _u32, _vp, _vp]),
+    "pt_blas_traversal_download": (_i, [_vp, _vp, _u32, _vp, _vp]),
     "pt_tlas_wide_download": (_i, [_vp, _vp, _u32, _vp, _vp]),
     "pt_tlas_build": (_i, [_vp, _vp, _u32, C.POINTER(_vp)]),
     "pt_tlas_destroy": (_i, [_vp]),
@@ -174,6 +175,15 @@ class BottomLevelAccelerationStructure:
         keys = np.zeros(self.prim_count, dtype=np.uint64)
         _check(self.ctx.lib.pt_blas_download(self.h, _p(nodes), _p(prims), _p(keys)))
         return nodes, prims, keys
+
+    def download_traversal_tree(self):
+        """(binary nodes, primitive per leaf position) of the tree the wide nodes are derived from."""
+        cnt = C.c_uint32(0)
+        _check(self.ctx.lib.pt_blas_traversal_download(self.h, None, 0, None, C.byref(cnt)))
+        nodes = np.zeros(cnt.value, dtype=abi.BVH_NODE)
+        prims = np.zeros(self.prim_count, dtype=np.uint32)
+        _check(self.ctx.lib.pt_blas_traversal_download(self.h, _p(nodes), cnt.value, _p(prims), None))
+        return nodes, prims
 
     def download_wide(self):
         """(wide nodes, depth) of the traversal layout."""

@@ -28,6 +28,8 @@ def wide_lib():
     lib = C.CDLL(LIB)
     lib.pt_wide_collapse_host.restype = C.c_uint32
     lib.pt_wide_collapse_host.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+    lib.pt_sah_build_host_c.restype = C.c_uint32
+    lib.pt_sah_build_host_c.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.pt_wide_candidates_host.restype = C.c_uint32
     lib.pt_wide_candidates_host.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_uint32]
     return lib
@@ -176,6 +178,113 @@ def test_rays_reach_the_triangle_they_hit(name, n, request, wide_lib):
     assert n_hit > n // 20
 
 
+def prim_boxes_in_index_order(blas):
+    """Padded primitive boxes [n, 6] in primitive order, in binary32 like the builders compute them."""
+    v = blas.vertices["pos"]
+    idx = blas.indices[:3 * blas.prim_count].reshape(-1, 3)
+    p = v[idx]
+    d = np.float32(blas.delta())
+    return np.ascontiguousarray(np.concatenate([(p.min(axis=1) - d), (p.max(axis=1) + d)], axis=1).astype(np.float32))
+
+
+def sah_host(lib, boxes, max_leaf=4):
+    n = len(boxes)
+    lo = np.ascontiguousarray(boxes[:, :3].min(axis=0)); hi = np.ascontiguousarray(boxes[:, 3:].max(axis=0))
+    nodes = np.zeros(n, dtype=abi.BVH_NODE)
+    order = np.zeros(n, dtype=np.uint32)
+    cnt = lib.pt_sah_build_host_c(boxes.ctypes.data, n, max_leaf, lo.ctypes.data, hi.ctypes.data, nodes.ctypes.data, order.ctypes.data)
+    return nodes[:cnt].copy(), order
+
+
+def check_binary_tree(nodes, order, boxes, max_leaf):
+    """Every primitive in exactly one leaf, every node referenced once, child boxes = exact unions."""
+    n = len(order)
+    assert sorted(order.tolist()) == list(range(n))
+    seen = np.zeros(n, np.int32)
+    node_seen = np.zeros(len(nodes), np.int32)
+    node_seen[0] = 1
+
+    def visit(i):
+        nd = nodes[i]
+        lo_all, hi_all = None, None
+        for c, lo, hi in ((int(nd["c0"]), nd["lo0"], nd["hi0"]), (int(nd["c1"]), nd["lo1"], nd["hi1"])):
+            assert c != EMPTY
+            if c >= 0:
+                node_seen[c] += 1
+                blo, bhi = visit(c)
+            else:
+                code = (~c) & 0xFFFFFFFF
+                first, cnt = code >> 3, (code & 7) + 1
+                assert cnt <= max_leaf
+                seen[first:first + cnt] += 1
+                b = boxes[order[first:first + cnt]]
+                blo, bhi = b[:, :3].min(axis=0), b[:, 3:].max(axis=0)
+            assert np.array_equal(blo, lo) and np.array_equal(bhi, hi)
+            lo_all = blo if lo_all is None else np.minimum(lo_all, blo)
+            hi_all = bhi if hi_all is None else np.maximum(hi_all, bhi)
+        return lo_all, hi_all
+
+    import sys
+    sys.setrecursionlimit(100000)
+    visit(0)
+    assert np.all(seen == 1) and np.all(node_seen == 1)
+
+
+def sah_cost(nodes):
+    """Sum of child-box areas of inner children relative to the root box."""
+    def area(lo, hi):
+        d = np.maximum(hi - lo, 0).astype(np.float64)
+        return d[..., 0] * d[..., 1] + d[..., 1] * d[..., 2] + d[..., 2] * d[..., 0]
+    root = area(np.minimum(nodes["lo0"][0], nodes["lo1"][0]), np.maximum(nodes["hi0"][0], nodes["hi1"][0]))
+    c = 1.0
+    for ck, lo, hi in (("c0", "lo0", "hi0"), ("c1", "lo1", "hi1")):
+        inner = nodes[ck] >= 0
+        c += area(nodes[lo][inner], nodes[hi][inner]).sum() / root
+    return c
+
+
+@pytest.mark.parametrize("name", ["cornell", "cube", "soup", "dragon"])
+def test_sah_tree_is_a_partition_with_exact_boxes(name, request, wide_lib):
+    scene = request.getfixturevalue(name)
+    orc = O.OracleScene(scene)
+    done = set()
+    for b in orc.blases:
+        key = (b.indices.ctypes.data, b.prim_count)
+        if key in done or b.prim_count < 2:
+            continue
+        done.add(key)
+        boxes = prim_boxes_in_index_order(b)
+        nodes, order = sah_host(wide_lib, boxes)
+        check_binary_tree(nodes, order, boxes, 4)
+        # and the wide nodes derived from it are conservative
+        wide, depth = collapse(wide_lib, nodes)
+        lo, hi = boxes[order][:, :3], boxes[order][:, 3:]
+        check_wide(wide, depth, lo, hi, b.prim_count)
+        if b.prim_count > 1000:
+            assert sah_cost(nodes) < 0.92 * sah_cost(b.nodes())      # what the second tree is for
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["cornell", "soup", "dragon", "stacked"])
+def test_gpu_sah_builder_matches_host_twin(name, request, wide_lib):
+    """Same decisions, level order and numbering on both sides: nodes and leaf order agree byte for byte."""
+    from pt_amd import hip
+    import oracle as O2
+    scene = request.getfixturevalue(name)
+    orc = O2.OracleScene(scene)
+    r = hip.Renderer(scene, 32, 32)
+    try:
+        for b, ob in zip(r.blases, orc.blases):
+            if ob.prim_count < 2:
+                continue
+            nodes, order = b.download_traversal_tree()
+            want_nodes, want_order = sah_host(wide_lib, prim_boxes_in_index_order(ob))
+            assert np.array_equal(order, want_order)
+            assert nodes.tobytes() == want_nodes.tobytes()
+    finally:
+        r.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["cornell", "soup", "dragon"])
 def test_gpu_builder_matches_host_collapse(name, request, wide_lib):
@@ -186,7 +295,7 @@ def test_gpu_builder_matches_host_collapse(name, request, wide_lib):
     r = hip.Renderer(scene, 32, 32)
     try:
         for b in r.blases:
-            nodes, _, _ = b.download()
+            nodes, _ = b.download_traversal_tree()
             got, depth = b.download_wide()
             want, want_depth = collapse(wide_lib, nodes)
             assert depth == want_depth and got.tobytes() == want.tobytes()
