@@ -438,11 +438,10 @@ __global__ void k_sah_root(const uint32_t* __restrict__ root_ord, uint32_t n, Pt
     tasks[0] = t;
 }
 
-__global__ void k_sah_reset(uint32_t m, uint32_t* __restrict__ cb, SahBinsOrd* __restrict__ bins)
+__global__ void k_sah_reset(uint32_t m, SahBinsOrd* __restrict__ bins)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t per = sizeof(SahBinsOrd) / 4;
-    if (i < m * 6) cb[i] = (i % 6) < 3 ? 0xFFFFFFFFu : 0u;
     if (i < m * per) {
         const uint32_t w = i % per;
         uint32_t* p = (uint32_t*)bins + i;
@@ -451,23 +450,8 @@ __global__ void k_sah_reset(uint32_t m, uint32_t* __restrict__ cb, SahBinsOrd* _
     }
 }
 
-__global__ void k_sah_centroids(uint32_t n, const uint32_t* __restrict__ ids, const float* __restrict__ boxes,
-                                const uint32_t* __restrict__ task_of, uint32_t t_lo, uint32_t t_hi, uint32_t* __restrict__ cb)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t t = task_of[i];
-    if (t == PT_SAH_NONE || t < t_lo || t >= t_hi) return;
-    const float* x = boxes + 6 * (size_t)ids[i];
-    uint32_t* c = cb + 6 * (size_t)(t - t_lo);
-    for (int k = 0; k < 3; ++k) {
-        const uint32_t o = f2ord(pt_sah_centroid(x, k));
-        atomicMin(&c[k], o); atomicMax(&c[3 + k], o);
-    }
-}
-
 __global__ void k_sah_bins(uint32_t n, const uint32_t* __restrict__ ids, const float* __restrict__ boxes,
-                           const uint32_t* __restrict__ task_of, uint32_t t_lo, uint32_t t_hi, const uint32_t* __restrict__ cb,
+                           const uint32_t* __restrict__ task_of, uint32_t t_lo, uint32_t t_hi, const PtSahTask* __restrict__ tasks,
                            SahBinsOrd* __restrict__ bins)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -475,10 +459,9 @@ __global__ void k_sah_bins(uint32_t n, const uint32_t* __restrict__ ids, const f
     const uint32_t t = task_of[i];
     if (t == PT_SAH_NONE || t < t_lo || t >= t_hi) return;
     const float* x = boxes + 6 * (size_t)ids[i];
-    const uint32_t* c = cb + 6 * (size_t)(t - t_lo);
     SahBinsOrd& B = bins[t - t_lo];
     for (int ax = 0; ax < 3; ++ax) {
-        const float clo = ord2f(c[ax]), chi = ord2f(c[3 + ax]);
+        const float clo = tasks[t].lo[ax], chi = tasks[t].hi[ax];     // bins span the range's box
         if (!(chi > clo)) continue;
         const int q = pt_sah_bin_of(x, ax, clo, pt_sah_scale(clo, chi));
         atomicAdd(&B.cnt[ax][q], 1u);
@@ -486,7 +469,7 @@ __global__ void k_sah_bins(uint32_t n, const uint32_t* __restrict__ ids, const f
     }
 }
 
-__global__ void k_sah_decide(uint32_t t_lo, uint32_t t_hi, PtSahTask* __restrict__ tasks, const uint32_t* __restrict__ cb,
+__global__ void k_sah_decide(uint32_t t_lo, uint32_t t_hi, PtSahTask* __restrict__ tasks,
                              const SahBinsOrd* __restrict__ bins, uint32_t max_leaf, const float* __restrict__ boxes,
                              const uint32_t* __restrict__ ids, uint32_t* __restrict__ inner)
 {
@@ -506,7 +489,7 @@ __global__ void k_sah_decide(uint32_t t_lo, uint32_t t_hi, PtSahTask* __restrict
         }
     }
     float c6[6];
-    for (int k = 0; k < 6; ++k) c6[k] = ord2f(cb[6 * (size_t)(t - t_lo) + k]);
+    for (int k = 0; k < 3; ++k) { c6[k] = task.lo[k]; c6[3 + k] = task.hi[k]; }
     pt_sah_decide(task, B, c6, max_leaf);
     if (task.kind == 2) pt_sah_positional_boxes(task, boxes, ids);
     tasks[t] = task;
@@ -632,12 +615,12 @@ int pt_build_sah(PtContext* ctx, const float* boxes, uint32_t n, uint32_t max_le
     DevMem mem;
     const uint32_t kBatch = 32768;                      // ranges whose bins are resident at once (44 MB)
     uint32_t *ids_a = nullptr, *ids_b = nullptr, *tof_a = nullptr, *tof_b = nullptr, *flags = nullptr, *left = nullptr;
-    uint32_t *inner = nullptr, *offsets = nullptr, *total = nullptr, *cb = nullptr;
+    uint32_t *inner = nullptr, *offsets = nullptr, *total = nullptr;
     PtSahTask *tasks_a = nullptr, *tasks_b = nullptr; SahBinsOrd* bins = nullptr; PtBvhNode* nodes = nullptr; uint32_t* sums = nullptr;
     hipError_t e = hipSuccess;
     if ((e = mem.alloc(&ids_a, n)) || (e = mem.alloc(&ids_b, n)) || (e = mem.alloc(&tof_a, n)) || (e = mem.alloc(&tof_b, n)) ||
         (e = mem.alloc(&flags, n)) || (e = mem.alloc(&left, n)) || (e = mem.alloc(&inner, n)) || (e = mem.alloc(&offsets, n)) ||
-        (e = mem.alloc(&total, 4)) || (e = mem.alloc(&cb, (size_t)6 * kBatch)) || (e = mem.alloc(&tasks_a, n)) || (e = mem.alloc(&tasks_b, n)) ||
+        (e = mem.alloc(&total, 4)) || (e = mem.alloc(&tasks_a, n)) || (e = mem.alloc(&tasks_b, n)) ||
         (e = mem.alloc(&bins, kBatch)) || (e = mem.alloc(&nodes, n)) || (e = mem.alloc(&sums, div_up(n, kBlock) + 1))) {
         pt_set_error("pt_build_sah: hipMalloc failed: %s", hipGetErrorString(e)); return PT_ERROR_OUT_OF_MEMORY;
     }
@@ -650,10 +633,9 @@ int pt_build_sah(PtContext* ctx, const float* boxes, uint32_t n, uint32_t max_le
         if (++levels > 4096 || m > n || node_base >= n) { pt_set_error("pt_build_sah: did not converge"); return PT_ERROR_HIP; }
         for (uint32_t t_lo = 0; t_lo < m; t_lo += kBatch) {
             const uint32_t t_hi = t_lo + kBatch < m ? t_lo + kBatch : m, mb = t_hi - t_lo;
-            k_sah_reset<<<div_up(mb * (uint32_t)(sizeof(SahBinsOrd) / 4), kBlock), kBlock, 0, st>>>(mb, cb, bins);
-            k_sah_centroids<<<nb, kBlock, 0, st>>>(n, ids_a, boxes, tof_a, t_lo, t_hi, cb);
-            k_sah_bins<<<nb, kBlock, 0, st>>>(n, ids_a, boxes, tof_a, t_lo, t_hi, cb, bins);
-            k_sah_decide<<<div_up(mb, 64), 64, 0, st>>>(t_lo, t_hi, tasks_a, cb, bins, max_leaf, boxes, ids_a, inner);
+            k_sah_reset<<<div_up(mb * (uint32_t)(sizeof(SahBinsOrd) / 4), kBlock), kBlock, 0, st>>>(mb, bins);
+            k_sah_bins<<<nb, kBlock, 0, st>>>(n, ids_a, boxes, tof_a, t_lo, t_hi, tasks_a, bins);
+            k_sah_decide<<<div_up(mb, 64), 64, 0, st>>>(t_lo, t_hi, tasks_a, bins, max_leaf, boxes, ids_a, inner);
         }
         int rc = scan_exclusive(st, mem, inner, offsets, m, total, sums);
         if (rc) return rc;

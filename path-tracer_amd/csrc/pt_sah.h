@@ -5,8 +5,10 @@
 // the canonical Morton tree stays the structure that is compared with the oracle.
 //
 // A node over the primitive range [a, b) bins the primitives by centroid into PT_SAH_BINS bins per
-// axis, takes the split with the smallest area(L) * n(L) + area(R) * n(R) (first minimum in
-// axis-major, bin-ascending order) and partitions the range stably.  A range of at most max_leaf
+// axis (the bins span the range's box: binning over the centroid bounds instead costs a pass of
+// heavily contended atomics per level and gave the same tree cost), takes the split with the
+// smallest area(L) * n(L) + area(R) * n(R) (first minimum in axis-major, bin-ascending order) and
+// partitions the range stably.  A range of at most max_leaf
 // primitives becomes a leaf when n * area <= area + best (the root never does); a range whose
 // centroids coincide is split by position.
 #pragma once
@@ -46,7 +48,7 @@ PT_HD static inline int pt_sah_bin_of(const float* box, int axis, float clo, flo
     return q < 0 ? 0 : (q >= PT_SAH_BINS ? PT_SAH_BINS - 1 : q);
 }
 
-// Fills the decision fields of `t` from its bins and centroid bounds (cb: lo[3], hi[3]).
+// Fills the decision fields of `t` from its bins; cb (lo[3], hi[3]) is the interval the bins span.
 PT_HD static inline void pt_sah_decide(PtSahTask& t, const PtSahBinsF& B, const float cb[6], uint32_t max_leaf)
 {
     const uint32_t n = t.b - t.a;
@@ -126,9 +128,9 @@ static inline void pt_sah_build_host(const float* boxes, uint32_t n, uint32_t ma
     while (!level.empty()) {
         next.clear();
         for (PtSahTask& t : level) {
-            PtSahBinsF B; float cb[6] = { inf, inf, inf, -inf, -inf, -inf };
+            PtSahBinsF B; float cb[6];
+            for (int k = 0; k < 3; ++k) { cb[k] = t.lo[k]; cb[3 + k] = t.hi[k]; }     // bins span the range's box
             for (int ax = 0; ax < 3; ++ax) for (int q = 0; q < PT_SAH_BINS; ++q) { B.cnt[ax][q] = 0; for (int k = 0; k < 3; ++k) { B.lo[ax][q][k] = inf; B.hi[ax][q][k] = -inf; } }
-            for (uint32_t i = t.a; i < t.b; ++i) { const float* x = boxes + 6 * (size_t)ids_out[i]; for (int k = 0; k < 3; ++k) { const float c = pt_sah_centroid(x, k); cb[k] = fminf(cb[k], c); cb[3 + k] = fmaxf(cb[3 + k], c); } }
             for (int ax = 0; ax < 3; ++ax) {
                 if (!(cb[3 + ax] > cb[ax])) continue;
                 const float sc = pt_sah_scale(cb[ax], cb[3 + ax]);
