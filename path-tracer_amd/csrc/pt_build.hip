@@ -450,22 +450,47 @@ __global__ void k_sah_reset(uint32_t m, SahBinsOrd* __restrict__ bins)
     }
 }
 
-__global__ void k_sah_bins(uint32_t n, const uint32_t* __restrict__ ids, const float* __restrict__ boxes,
-                           const uint32_t* __restrict__ task_of, uint32_t t_lo, uint32_t t_hi, const PtSahTask* __restrict__ tasks,
-                           SahBinsOrd* __restrict__ bins)
+// Positions are contiguous per range, so most of a block's primitives belong to the range of its first
+// one: those are binned in LDS and flushed once (a few hundred global atomics per block instead of 21
+// per primitive); the others go to global memory directly.
+__global__ void __launch_bounds__(kBlock)
+k_sah_bins(uint32_t n, const uint32_t* __restrict__ ids, const float* __restrict__ boxes,
+           const uint32_t* __restrict__ task_of, uint32_t t_lo, uint32_t t_hi, const PtSahTask* __restrict__ tasks,
+           SahBinsOrd* __restrict__ bins)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t t = task_of[i];
-    if (t == PT_SAH_NONE || t < t_lo || t >= t_hi) return;
-    const float* x = boxes + 6 * (size_t)ids[i];
-    SahBinsOrd& B = bins[t - t_lo];
-    for (int ax = 0; ax < 3; ++ax) {
-        const float clo = tasks[t].lo[ax], chi = tasks[t].hi[ax];     // bins span the range's box
-        if (!(chi > clo)) continue;
-        const int q = pt_sah_bin_of(x, ax, clo, pt_sah_scale(clo, chi));
-        atomicAdd(&B.cnt[ax][q], 1u);
-        for (int k = 0; k < 3; ++k) { atomicMin(&B.lo[ax][q][k], f2ord(x[k])); atomicMax(&B.hi[ax][q][k], f2ord(x[3 + k])); }
+    constexpr uint32_t kWords = sizeof(SahBinsOrd) / 4, kBoxWords = 3 * PT_SAH_BINS * 3;
+    __shared__ SahBinsOrd s_bins;
+    __shared__ uint32_t s_task;
+    uint32_t* sw = (uint32_t*)&s_bins;
+    for (uint32_t w = threadIdx.x; w < kWords; w += kBlock) sw[w] = w < kBoxWords ? 0xFFFFFFFFu : 0u;
+    const uint32_t first = blockIdx.x * blockDim.x;
+    if (threadIdx.x == 0) s_task = first < n ? task_of[first] : PT_SAH_NONE;
+    __syncthreads();
+    uint32_t t0 = s_task;
+    if (t0 != PT_SAH_NONE && (t0 < t_lo || t0 >= t_hi)) t0 = PT_SAH_NONE;
+    const uint32_t i = first + threadIdx.x;
+    if (i < n) {
+        const uint32_t t = task_of[i];
+        if (t != PT_SAH_NONE && t >= t_lo && t < t_hi) {
+            const float* x = boxes + 6 * (size_t)ids[i];
+            SahBinsOrd& B = t == t0 ? s_bins : bins[t - t_lo];
+            for (int ax = 0; ax < 3; ++ax) {
+                const float clo = tasks[t].lo[ax], chi = tasks[t].hi[ax];     // bins span the range's box
+                if (!(chi > clo)) continue;
+                const int q = pt_sah_bin_of(x, ax, clo, pt_sah_scale(clo, chi));
+                atomicAdd(&B.cnt[ax][q], 1u);
+                for (int k = 0; k < 3; ++k) { atomicMin(&B.lo[ax][q][k], f2ord(x[k])); atomicMax(&B.hi[ax][q][k], f2ord(x[3 + k])); }
+            }
+        }
+    }
+    __syncthreads();
+    if (t0 == PT_SAH_NONE) return;
+    uint32_t* gw = (uint32_t*)&bins[t0 - t_lo];
+    for (uint32_t w = threadIdx.x; w < kWords; w += kBlock) {
+        const uint32_t v = sw[w];
+        if (w < kBoxWords) { if (v != 0xFFFFFFFFu) atomicMin(&gw[w], v); }
+        else if (w < 2 * kBoxWords) { if (v != 0u) atomicMax(&gw[w], v); }
+        else if (v != 0u) atomicAdd(&gw[w], v);
     }
 }
 
