@@ -143,7 +143,8 @@ int pt_blas_info(const PtBlas* blas, PtAsInfo* out);
 /* Copies the built structure to the host (any pointer may be NULL): nodes[node_count],
  * leaf_prims[prim_count] (primitive ids in sorted order), sorted_keys[prim_count]. */
 int pt_blas_download(const PtBlas* blas, PtBvhNode* nodes, uint32_t* leaf_prims, uint64_t* sorted_keys);
-/* The layout the kernels traverse, derived on the GPU from the binary nodes above: 64-byte nodes
+/* The layout the kernels traverse, derived on the GPU from a binary tree (pt_blas_traversal_download
+ * below; for a TLAS its Morton tree): 64-byte nodes
  * with four children whose boxes are quantised to 8 bits on a per-node power-of-two grid
  * { float origin[3]; float step_x; int32 child[4]; uint32 q[6] (lo.x lo.y lo.z hi.x hi.y hi.z, byte k
  * = child k); float step_y, step_z }, numbered breadth first, references local to the structure.

@@ -1,20 +1,22 @@
 // pt_traverse_sched.h -- wave-scheduled persistent traversal.
 //
-// Measured on incoherent bounces with one-ray-per-lane-until-the-batch-ends traversal: only 14-19 %
-// of the vector lanes do useful work (SQ_THREAD_CYCLES_VALU / 64 / SQ_ACTIVE_INST_VALU), because
+// Measured on incoherent bounces with one-ray-per-lane-until-the-batch-ends traversal of binary
+// nodes: only 14-19 % of the vector lanes do useful work (SQ_THREAD_CYCLES_VALU / 64 / SQ_ACTIVE_INST_VALU), because
 // (a) the 64 rays of a batch need very different numbers of steps and the wave runs as long as its
 //     longest ray, and
 // (b) lanes sit in different phases (box step, triangle test, instance entry) and every phase present
 //     in the wave is executed on every iteration, each at its own low lane count.
 // This kernel removes both:
 // (a) ray replacement: a lane whose ray has finished takes the next ray of the wave's private chunk
-//     (256 slots claimed with one atomic), so lanes stay populated until the queue is empty;
+//     (a shard's fair share, at most 256 slots, claimed with one atomic), so lanes stay populated
+//     until the queue is empty;
 // (b) phase voting: the wave executes ONE phase at a time -- the one its lanes vote for, for a few
 //     steps in a row -- and the other lanes wait, so the long phases (triangle test, instance entry)
 //     only run once enough lanes have accumulated in them.
 // Per-lane state is kept small (one ray space, the best hit, six scalars): the world-space ray is
 // re-read from the queue when a lane leaves an instance, and the triangle test rebuilds its axis
-// permutation from the ray, which keeps the kernel at six waves per SIMD.
+// permutation from the ray, which keeps the kernel within the 128 registers of four waves per SIMD
+// without spills.
 // The per-lane arithmetic (slab test, gated watertight triangle test, hit ordering) is the one in
 // pt_device.h, so results are bit-identical to the plain traversal.
 #pragma once

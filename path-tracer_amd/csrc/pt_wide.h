@@ -12,14 +12,15 @@
 // Traversal layout: 4-wide nodes with child boxes quantised to 8 bits on a per-node grid (64 bytes
 // for four children instead of 64 bytes for two).  The traversal kernels are bound by the number of
 // 16-byte-per-lane loads the texture path has to serve for scattered node fetches, so bytes per
-// child are what counts.  A wide node stands for a node of the canonical binary tree; its entries
+// child are what counts.  A wide node stands for a node of a binary tree (the binned-SAH tree of
+// pt_sah.h for a BLAS, the Morton tree for a TLAS); its entries
 // are found by opening that node and then, while fewer than four entries exist, the inner entry
 // with the largest surface area.  Quantisation only ever grows a box
 // (checked with the same fma the kernels use to expand it), so the set of triangles a ray is tested
 // against can grow but the closest hit cannot change.
 struct PtWide4 {
     float origin[3];
-    float scale_x;          // grid steps are powers of two
+    float scale_x;          // grid steps are powers of two (kept as floats: no unpacking in the kernels)
     int32_t child[4];       // >= 0 wide node, < 0 leaf (~c = first << 3 | count - 1), INT32_MIN empty
     uint32_t q[6];          // lo.x, lo.y, lo.z, hi.x, hi.y, hi.z; byte k of each word belongs to child k
     float scale_y, scale_z;
