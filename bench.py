@@ -134,6 +134,7 @@ def main():
     # that every internal stream has allocated its path queues before the clock starts
     run_steps(r, accum.data_ptr(), max(args.warmup, args.frames_in_flight), 1_000_000, rank, world, args.spp, args.max_depth)
     r.ctx.sync()                    # frames in flight still add to the image
+    sharding.allreduce_sum(accum)   # the collective's first call sets up its communicator and buffers: not timed
     accum.zero_()
     r.reset_stats()
     # the dominant kernel (intersect) is bracketed by HIP events on the streams it runs on, during the timed steps
