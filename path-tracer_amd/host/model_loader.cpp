@@ -179,7 +179,7 @@ std::shared_ptr<Model> ModelLoader::LoadGltf(const std::string& path)
         ImageCreation creation {};
         creation.name = uri;
         ResourceHandle<Image> handle {};
-        if (LoadPngRGBA8(directory + "/" + uri, creation.data, creation.width, creation.height)) handle = _bindlessResources->Images().Create(creation);
+        if (LoadImageRGBA8(directory + "/" + uri, creation.data, creation.width, creation.height)) handle = _bindlessResources->Images().Create(creation);
         else std::fprintf(stderr, "[GLTF] Failed to load data from image [%s] from path [%s/%s]\n", uri.c_str(), directory.c_str(), uri.c_str());
         model->textures.push_back(handle);
         return handle;

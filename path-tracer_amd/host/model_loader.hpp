@@ -50,6 +50,9 @@ struct Model {
 static_assert(sizeof(Model::Vertex) == 32, "Vertex must match the device layout");
 
 bool LoadPngRGBA8(const std::string& path, std::vector<uint8_t>& rgba, uint32_t& width, uint32_t& height);
+bool LoadJpegRGBA8(const std::string& path, std::vector<uint8_t>& rgba, uint32_t& width, uint32_t& height);
+// stbi_load(path, &w, &h, &channels, 4) of source/model_loader.cpp:25: PNG or JPEG by signature, RGBA8, top row first
+bool LoadImageRGBA8(const std::string& path, std::vector<uint8_t>& rgba, uint32_t& width, uint32_t& height);
 
 class ModelLoader {
 public:

@@ -106,3 +106,76 @@ def test_frame_schedule_partitions_the_frames():
         for n in (1, 7, 16):
             got = sorted(f for r in range(world) for f in sharding.frames_for_rank(r, world, n, first_frame=3))
             assert got == list(range(3, 3 + n))
+
+
+# ---- C++ image decoders (path-tracer_amd/host/image_png.cpp, image_jpeg.cpp) ------------------------
+def _decode_cpp(path):
+    import ctypes as C
+    lib_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "path-tracer_amd", "lib", "libpt_host.so")
+    if not os.path.exists(lib_path):
+        pytest.fail("libpt_host.so is not built (make -C path-tracer_amd/host)")
+    lib = C.CDLL(lib_path)
+    lib.pt_host_decode_image.argtypes = [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_void_p, C.c_size_t]
+    w, h = C.c_uint32(), C.c_uint32()
+    if lib.pt_host_decode_image(str(path).encode(), C.byref(w), C.byref(h), None, 0):
+        return None
+    out = np.zeros((h.value, w.value, 4), np.uint8)
+    assert lib.pt_host_decode_image(str(path).encode(), None, None, out.ctypes.data, out.nbytes) == 0
+    return out
+
+
+def test_jpeg_decoder_against_another_decoder(tmp_path, cube):
+    """Baseline and progressive streams, 4:4:4 / 4:2:2 / 4:2:0 and grey, two qualities, restart
+    intervals, odd sizes: within a few levels of Pillow's decoder (inverse DCT, chroma upsampling and
+    colour conversion round differently from decoder to decoder; no bit-exact target exists here)."""
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(0)
+    photo = np.ascontiguousarray(cube.tables.images[1][:301, :277, :3])
+    noise = rng.uniform(0, 255, size=(97, 131, 3)).astype(np.uint8)
+    cases = []
+    for name, img in (("photo", photo), ("noise", noise)):
+        for prog in (False, True):
+            for q in (35, 90):
+                for sub in (0, 1, 2):
+                    cases.append((f"{name}_{int(prog)}_{q}_{sub}", Image.fromarray(img), dict(quality=q, progressive=prog, subsampling=sub)))
+                cases.append((f"{name}_{int(prog)}_{q}_grey", Image.fromarray(img).convert("L"), dict(quality=q, progressive=prog)))
+    cases.append(("restart", Image.fromarray(photo), dict(quality=80, restart_marker_blocks=7)))
+    cases.append(("restart_prog", Image.fromarray(photo), dict(quality=80, progressive=True, restart_marker_rows=1)))
+    for name, im, kw in cases:
+        path = tmp_path / f"{name}.jpg"
+        im.save(path, "JPEG", **kw)
+        got = _decode_cpp(path)
+        assert got is not None, name
+        want = np.asarray(Image.open(path).convert("RGBA"))
+        assert got.shape == want.shape, name
+        diff = np.abs(got.astype(np.int32) - want.astype(np.int32))
+        assert diff.max() <= 4 and diff.mean() < 0.1, (name, int(diff.max()), float(diff.mean()))
+        assert np.all(got[..., 3] == 255)
+    # not a JPEG, truncated JPEG
+    bad = tmp_path / "bad.jpg"
+    bad.write_bytes(b"\xff\xd8\xff\xe0 not a jpeg")
+    assert _decode_cpp(bad) is None
+    data = (tmp_path / "photo_0_90_2.jpg").read_bytes()
+    (tmp_path / "cut.jpg").write_bytes(data[:200])
+    assert _decode_cpp(tmp_path / "cut.jpg") is None
+
+
+def test_reference_jpeg_textures_decode():
+    """The dragon's textures (baseline checkerboard.jpg, progressive Dragon_ThicknessMap.jpg)."""
+    Image = pytest.importorskip("PIL.Image")
+    d = "/root/reference/assets/dragon"
+    if not os.path.isdir(d):
+        pytest.skip("reference assets are not mounted")
+    for f in ("checkerboard.jpg", "Dragon_ThicknessMap.jpg"):
+        got = _decode_cpp(os.path.join(d, f))
+        want = np.asarray(Image.open(os.path.join(d, f)).convert("RGBA"))
+        assert got is not None and got.shape == want.shape == (2048, 2048, 4)
+        assert np.abs(got.astype(np.int32) - want.astype(np.int32)).max() <= 2
+
+
+def test_png_decoder_matches_fixture(cube):
+    d = "/root/reference/assets/cube"
+    if not os.path.isdir(d):
+        pytest.skip("reference assets are not mounted")
+    got = _decode_cpp(os.path.join(d, "Cube_BaseColor.png"))
+    assert got is not None and np.array_equal(got, cube.tables.images[1])
