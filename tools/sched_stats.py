@@ -11,7 +11,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "path-tracer_amd"))
 from pt_amd import hip, procedural
 
-scene = procedural.dragon_standin()
+if len(sys.argv) > 1 and sys.argv[1] == "cornell":
+    from pt_amd.scene import Scene
+    scene = Scene.load_npz(os.path.join(ROOT, "tests", "golden", "scene_cornell.npz"))
+else:
+    scene = procedural.dragon_standin()
 W, H, SPP = 1920, 1080, 4
 r = hip.Renderer(scene, W, H)
 lib = r.ctx.lib
