@@ -26,6 +26,13 @@ def cube():
 
 
 @pytest.fixture(scope="session")
+def helmet():
+    """FlightHelmet geometry (5 instances, 94,722 triangles) with reduced base-colour textures."""
+    from pt_amd.scene import Scene
+    return Scene.load_npz(os.path.join(GOLDEN, "scene_helmet.npz"))
+
+
+@pytest.fixture(scope="session")
 def dragon():
     from pt_amd import procedural
     return procedural.dragon_standin()

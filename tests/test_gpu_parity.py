@@ -30,7 +30,7 @@ def _float_eq(a, b):
     return a.shape == b.shape and bool(np.all((a == b) | (np.isnan(a) & np.isnan(b))))
 
 
-@pytest.mark.parametrize("name", ["cornell", "cube", "soup", "dragon"])
+@pytest.mark.parametrize("name", ["cornell", "cube", "soup", "dragon", "helmet"])
 def test_bvh_topology_bit_exact(name, request):
     scene = request.getfixturevalue(name)
     orc = _oracle(scene)
@@ -106,6 +106,53 @@ def test_render_frame_bit_exact(name, w, h, spp, schedule, request, monkeypatch)
         assert int(stats["paths"]) == 2 * w * h * spp
     finally:
         r.close()
+
+
+HELMET_CAMERA = dict(eye=(0.15, 0.1, 0.75), center=(0.0, 0.0, 0.0), fov_deg=50.0)
+
+
+@pytest.mark.parametrize("schedule", ["plain", "sched"])
+def test_helmet_textured_frame_bit_exact(helmet, schedule, monkeypatch):
+    """BASELINE config 3's scene (FlightHelmet: 5 instances, 94,722 triangles, four base-colour
+    textures sampled through the mesh's own UVs) with a camera that frames it: hit records of the
+    primary rays and two frames, bit for bit; then 1080p for the sample-count bookkeeping."""
+    monkeypatch.setenv("PT_HIP_TRAVERSAL", schedule)
+    import oracle as O
+    from pt_amd import camera
+    w, h, spp = 240, 200, 8
+    cam = camera.camera_uniform(w, h, **HELMET_CAMERA)
+    orc = _oracle(helmet)
+    r = _renderer(helmet, w, h, camera=cam)
+    try:
+        o = np.zeros((w * h, 3), np.float32); d = np.zeros((w * h, 3), np.float32)
+        for y in range(h):
+            for x in range(w):
+                o[y * w + x], d[y * w + x] = O.primary_ray(cam, w, h, x, y)
+        hg, tg = r.intersect(o, d)
+        ho, to = orc.tlas.intersect(o, d)
+        assert np.array_equal(hg, ho) and _float_eq(tg, to)
+        hit = ho["instance"] != 0xFFFFFFFF
+        assert hit.mean() > 0.1 and len(set(ho["instance"][hit].tolist())) >= 4
+        for frame in (0, 1):
+            r.render(spp=spp, max_depth=10, frame=frame)
+            want, _ = orc.render_frame(cam, w, h, frame=frame, spp=spp, threads=8)
+            assert _float_eq(r.last_result(), want)
+        # textured surfaces are not grey: the base-colour maps really are sampled
+        res = r.last_result()[hit.reshape(h, w)]
+        assert np.mean(np.abs(res[:, 0] - res[:, 2])) > 1e-3
+    finally:
+        r.close()
+    if schedule == "sched":
+        W, H = 1920, 1080
+        r = _renderer(helmet, W, H, camera=camera.camera_uniform(W, H, **HELMET_CAMERA))
+        try:
+            r.render(spp=4, frame=0)
+            s = r.stats()
+            assert int(s["paths"]) == W * H * 4 and int(s["rays_per_depth"][0]) == W * H * 4
+            res = r.last_result()
+            assert np.isfinite(res).all() and (res >= 0).all()
+        finally:
+            r.close()
 
 
 def test_exact_ties_between_instances(stacked, cornell):

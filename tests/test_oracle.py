@@ -144,7 +144,7 @@ def _check_bvh(nodes, leaf_prims, n_prims, max_leaf):
     assert sorted(leaf_prims.tolist()) == list(range(n_prims))
 
 
-@pytest.mark.parametrize("name", ["cornell", "cube", "soup", "dragon"])
+@pytest.mark.parametrize("name", ["cornell", "cube", "soup", "dragon", "helmet"])
 def test_bvh_is_a_partition(name, request):
     scene = request.getfixturevalue(name)
     orc = O.OracleScene(scene)
@@ -167,6 +167,21 @@ def test_bvh_traversal_equals_brute_force(name, n, request):
     hv, tv = orc.tlas.intersect(o, d, use_bvh=True)
     assert np.array_equal(hb, hv) and np.array_equal(tb, tv)
     assert (hv["instance"] != 0xFFFFFFFF).mean() > 0.02
+
+
+def test_helmet_bvh_equals_brute_force(helmet):
+    """Rays aimed at the FlightHelmet (it is 0.66 units tall around the origin)."""
+    orc = O.OracleScene(helmet)
+    rng = np.random.default_rng(4)
+    o = rng.uniform(-0.8, 0.8, size=(400, 3)).astype(np.float32)
+    tgt = rng.uniform(-0.15, 0.15, size=(400, 3)).astype(np.float32) * np.array([1, 2, 1], np.float32)
+    d = tgt - o
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    hb, tb = orc.tlas.intersect(o, d, use_bvh=False)
+    hv, tv = orc.tlas.intersect(o, d, use_bvh=True)
+    assert np.array_equal(hb, hv) and np.array_equal(tb, tv)
+    hit = hv["instance"] != 0xFFFFFFFF
+    assert hit.mean() > 0.3 and len(set(hv["instance"][hit].tolist())) >= 4
 
 
 def test_exact_ties_go_to_the_lowest_instance(stacked):

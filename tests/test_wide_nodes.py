@@ -243,7 +243,7 @@ def sah_cost(nodes):
     return c
 
 
-@pytest.mark.parametrize("name", ["cornell", "cube", "soup", "dragon"])
+@pytest.mark.parametrize("name", ["cornell", "cube", "soup", "dragon", "helmet"])
 def test_sah_tree_is_a_partition_with_exact_boxes(name, request, wide_lib):
     scene = request.getfixturevalue(name)
     orc = O.OracleScene(scene)
@@ -265,7 +265,7 @@ def test_sah_tree_is_a_partition_with_exact_boxes(name, request, wide_lib):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["cornell", "soup", "dragon", "stacked"])
+@pytest.mark.parametrize("name", ["cornell", "soup", "dragon", "stacked", "helmet"])
 def test_gpu_sah_builder_matches_host_twin(name, request, wide_lib):
     """Same decisions, level order and numbering on both sides: nodes and leaf order agree byte for byte."""
     from pt_amd import hip
