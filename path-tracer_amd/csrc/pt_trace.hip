@@ -1,6 +1,7 @@
 // pt_trace.hip -- the wavefront path-tracing pipeline that replaces vkCmdTraceRaysKHR
 // (source/renderer.cpp:122) and the three shaders it runs:
-//   generate   shaders/ray_gen.rgen:21-47   primary ray + per-sample seed + payload reset
+//   (generate) shaders/ray_gen.rgen:21-47   primary ray + per-sample seed + payload reset: no pass of its
+//              own; bounce 0 computes them from the path index where they are used
 //   intersect  shaders/ray_gen.rgen:54-65   traceRayEXT (software two-level BVH traversal)
 //   shade      shaders/closest_hit.rchit:55-86 and shaders/miss.rmiss:8-21, plus the
 //              bounce bookkeeping of ray_gen.rgen:67-68; survivors are compacted into the next queue
@@ -10,7 +11,8 @@
 //   q0 = (origin.xyz, bits(seed))   q1 = (direction.xyz, bits(path id))
 //   q2 = (currentWeight.rgb, -)     q3 = (hitValue.rgb, -)
 // so every lane moves 16 bytes per access and a wave moves 1 KiB per instruction.  The "path id" is the
-// slot of the path's final radiance, laid out [sample][pixel of the chunk].
+// slot of the path's final radiance, laid out [sample][pixel of the chunk].  The streams come into being
+// with the survivors of bounce 0; bounce 0 itself reads none of them.
 //
 // Ray queues are split into kShards independent shards, each with its own size and work counter
 // on its own 128-byte line.  A single queue head saturates at roughly 90 atomics per microsecond,
@@ -92,34 +94,54 @@ __device__ __forceinline__ void for_each_batch(uint32_t* __restrict__ counters, 
 // ------------------------------------------------------------------------------------------------
 struct PtCameraArg { float m[32]; };
 
-__global__ void __launch_bounds__(kBlock)
-k_generate(uint32_t n_paths, uint32_t pixel0, uint32_t spp, uint32_t W, uint32_t H, uint32_t frame, uint32_t seed_mode,
-           uint32_t shard_cap, PtCameraArg camera /* viewInverse, projInverse; by value: no copy to wait for */, float4* __restrict__ q0,
-           float4* __restrict__ q1, uint32_t* __restrict__ counters)
+// What bounce 0 needs to know about a path without any stored state: ray_gen.rgen:21-47 is a pure
+// function of the path index, so the primary ray is computed where it is traced and the seed where
+// it is first used; no generation pass writes 32 bytes per path for the next two kernels to read back.
+struct PtPrimaryArg {
+    PtCameraArg camera;     // viewInverse, projInverse; by value: no copy to wait for
+    uint32_t n_paths, pixel0, spp, W, H, frame, seed_mode;
+};
+
+// Path index of a queue slot at bounce 0 (inverse of slot_of_path); s = shard of the slot.
+__device__ __forceinline__ uint32_t path_of_slot(uint32_t slot, uint32_t s, uint32_t shard_cap)
 {
-    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q < kShards) counters[ctr_index(CTR_COUNT, 0, q)] = shard_count(n_paths, q);
-    if (q >= n_paths) return;
-    const uint32_t pixel = pixel0 + q / spp, s = q % spp;
-    const uint32_t px = pixel % W, py = pixel / W;
-    const float* VI = camera.m; const float* PI = camera.m + 16;
-    float uvx = ((float)px + 0.5f) / (float)W;
-    float uvy = ((float)py + 0.5f) / (float)H;
+    const uint32_t within = slot - s * shard_cap;
+    return (((within >> 6) * kShards + s) << 6) + (within & 63u);
+}
+
+// ray_gen.rgen:21-31: origin and direction of the primary ray of path q
+__device__ __forceinline__ void pt_primary_ray(const PtPrimaryArg& P, uint32_t q, float& ox, float& oy, float& oz, float& rx, float& ry, float& rz)
+{
+    const uint32_t pixel = P.pixel0 + q / P.spp;
+    const uint32_t px = pixel % P.W, py = pixel / P.W;
+    const float* VI = P.camera.m; const float* PI = P.camera.m + 16;
+    float uvx = ((float)px + 0.5f) / (float)P.W;
+    float uvy = ((float)py + 0.5f) / (float)P.H;
     float dx = uvx * 2.0f - 1.0f, dy = uvy * 2.0f - 1.0f;
     float tx = PT_FMA(PI[0], dx, PT_FMA(PI[4], dy, PI[8] + PI[12]));
     float ty = PT_FMA(PI[1], dx, PT_FMA(PI[5], dy, PI[9] + PI[13]));
     float tz = PT_FMA(PI[2], dx, PT_FMA(PI[6], dy, PI[10] + PI[14]));
     pt_normalize(tx, ty, tz);
-    float rx = PT_FMA(VI[0], tx, PT_FMA(VI[4], ty, VI[8] * tz));
-    float ry = PT_FMA(VI[1], tx, PT_FMA(VI[5], ty, VI[9] * tz));
-    float rz = PT_FMA(VI[2], tx, PT_FMA(VI[6], ty, VI[10] * tz));
-    uint32_t v1 = seed_mode == PT_SEED_CLOCK ? (uint32_t)clock64() : frame * spp + s;
-    uint32_t seed = pt_tea(py * W + px, v1);
-    const uint32_t i = slot_of_path(q, shard_cap);
-    q0[i] = make_float4(VI[12], VI[13], VI[14], __uint_as_float(seed));
-    // the path's result slot is sample-major, so that the per-pixel sum reads consecutive pixels together
-    q1[i] = make_float4(rx, ry, rz, __uint_as_float(s * (n_paths / spp) + q / spp));
-    // currentWeight = 1 and hitValue = 0 (ray_gen.rgen:44-48) are not stored: the first shade pass knows them
+    rx = PT_FMA(VI[0], tx, PT_FMA(VI[4], ty, VI[8] * tz));
+    ry = PT_FMA(VI[1], tx, PT_FMA(VI[5], ty, VI[9] * tz));
+    rz = PT_FMA(VI[2], tx, PT_FMA(VI[6], ty, VI[10] * tz));
+    ox = VI[12]; oy = VI[13]; oz = VI[14];
+}
+
+// ray_gen.rgen:38-40 (per-sample seed) and the slot of the path's final radiance, [sample][pixel of the
+// chunk] so that the per-pixel sum reads consecutive pixels together
+__device__ __forceinline__ void pt_primary_seed(const PtPrimaryArg& P, uint32_t q, uint32_t& seed, uint32_t& result_slot)
+{
+    const uint32_t in_chunk = q / P.spp, s = q % P.spp, pixel = P.pixel0 + in_chunk;
+    const uint32_t px = pixel % P.W, py = pixel / P.W;
+    const uint32_t v1 = P.seed_mode == PT_SEED_CLOCK ? (uint32_t)clock64() : P.frame * P.spp + s;
+    seed = pt_tea(py * P.W + px, v1);
+    result_slot = s * (P.n_paths / P.spp) + in_chunk;
+}
+
+__global__ void k_init_counts(uint32_t n_paths, uint32_t* __restrict__ counters)
+{
+    if (threadIdx.x < kShards) counters[ctr_index(CTR_COUNT, 0, threadIdx.x)] = shard_count(n_paths, threadIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -132,11 +154,13 @@ k_generate(uint32_t n_paths, uint32_t pixel0, uint32_t spp, uint32_t W, uint32_t
 // The level's size lives on the device, so the kernel decides: scheduled when the level holds at
 // least sched_min_rays rays (0 forces it, UINT32_MAX forces the plain schedule).
 // BY_ID: hit records go to hits[path id] (pt_intersect: caller's ray order) instead of the queue slot.
-template <bool BY_ID>
+// FIRST: bounce 0 of pt_trace; rays are computed from the path index (plain schedule, they are coherent).
+template <bool BY_ID, bool FIRST>
 __global__ void __launch_bounds__(kBlock, PT_INTERSECT_WAVES)
 k_intersect(PtTlasView tl, uint32_t* __restrict__ counters, uint32_t depth, uint32_t shard_cap,
             const float4* __restrict__ q0, const float4* __restrict__ q1, float tmin, float tmax,
-            PtHit* __restrict__ hits, float* __restrict__ t_out, int* __restrict__ spill, uint32_t sched_min_rays)
+            PtHit* __restrict__ hits, float* __restrict__ t_out, int* __restrict__ spill, uint32_t sched_min_rays,
+            PtPrimaryArg primary)
 {
     __shared__ int s_stack[PT_LDS_STACK][kBlock];
     PtStack stk;
@@ -144,16 +168,18 @@ k_intersect(PtTlasView tl, uint32_t* __restrict__ counters, uint32_t depth, uint
     stk.spill_base = spill;
     uint32_t total = counters[ctr_index(CTR_COUNT, depth, threadIdx.x & (kShards - 1))];   // lane s: shard s
     for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off);
-    if (total >= sched_min_rays) {
+    if (!FIRST && total >= sched_min_rays) {
         PtSchedQueue Q;
         Q.counters = counters; Q.shard_cap = shard_cap; Q.n_shards = kShards; Q.ctr_pad = kCtrPad;
         Q.count_base = ctr_index(CTR_COUNT, depth, 0); Q.work_base = ctr_index(CTR_WORK_INTERSECT, depth, 0);
         pt_traverse_sched<BY_ID>(tl, Q, stk, q0, q1, tmin, tmax, hits, t_out);
         return;
     }
-    for_each_batch<false>(counters, CTR_WORK_INTERSECT, depth, shard_cap, [&](uint32_t i, bool valid, uint32_t) {
+    for_each_batch<false>(counters, CTR_WORK_INTERSECT, depth, shard_cap, [&](uint32_t i, bool valid, uint32_t shard) {
         if (valid) {
-            const float4 o = q0[i], d = q1[i];
+            float4 o, d;
+            if (FIRST) { pt_primary_ray(primary, path_of_slot(i, shard, shard_cap), o.x, o.y, o.z, d.x, d.y, d.z); d.w = 0.0f; }
+            else { o = q0[i]; d = q1[i]; }
             PtHitRec h;
             pt_closest_hit(tl, stk, o.x, o.y, o.z, d.x, d.y, d.z, tmin, tmax, h);
             PtHit out; out.instance = h.inst; out.primitive = h.prim; out.u = h.u; out.v = h.v;
@@ -225,7 +251,7 @@ k_shade(const PtDevShadeInstance* __restrict__ shade_inst, uint32_t depth, uint3
         uint32_t* __restrict__ counters, uint32_t shard_cap, const PtHit* __restrict__ hits,
         const float4* __restrict__ q0, const float4* __restrict__ q1, const float4* __restrict__ q2, const float4* __restrict__ q3,
         float4* __restrict__ o0, float4* __restrict__ o1, float4* __restrict__ o2, float4* __restrict__ o3,
-        float4* __restrict__ path_result)
+        float4* __restrict__ path_result, PtPrimaryArg primary)
 {
     const uint32_t lane = threadIdx.x & 63;
     const float PI_F = 3.14159265f;
@@ -234,8 +260,9 @@ k_shade(const PtDevShadeInstance* __restrict__ shade_inst, uint32_t depth, uint3
         float4 no, nd, nw, nh;
         if (valid) {
             const PtHit h = hits[i];
-            const uint32_t seed_in = __float_as_uint(q0[i].w);
-            const uint32_t path = __float_as_uint(q1[i].w);
+            uint32_t seed_in, path;
+            if (FIRST) pt_primary_seed(primary, path_of_slot(i, shard, shard_cap), seed_in, path);
+            else { seed_in = __float_as_uint(q0[i].w); path = __float_as_uint(q1[i].w); }
             const float4 cw = FIRST ? make_float4(1.0f, 1.0f, 1.0f, 0.0f) : q2[i];
             float4 hv = FIRST ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : q3[i];
             if (h.instance == 0xFFFFFFFFu) {
@@ -534,9 +561,9 @@ int pt_intersect(PtContext* ctx, const PtTlas* tlas, uint32_t n, const float* or
     k_pack_rays<<<(n + kBlock - 1) / kBlock, kBlock, 0, st>>>(n, w.shard_cap, origins_dev, dirs_dev, w.q[0][0], w.q[0][1], w.counters);
     {
         // caller-supplied rays are treated as incoherent: scheduled above the threshold
-        const int blocks = persistent_blocks(ctx, (const void*)k_intersect<true>);
-        k_intersect<true><<<blocks, kBlock, 0, st>>>(view_of(tlas), w.counters, 0, w.shard_cap, w.q[0][0], w.q[0][1],
-                                                     tmin, tmax, hits_dev, t_dev, w.spill, sched_threshold(ctx, 1));
+        const int blocks = persistent_blocks(ctx, (const void*)k_intersect<true, false>);
+        k_intersect<true, false><<<blocks, kBlock, 0, st>>>(view_of(tlas), w.counters, 0, w.shard_cap, w.q[0][0], w.q[0][1],
+                                                            tmin, tmax, hits_dev, t_dev, w.spill, sched_threshold(ctx, 1), PtPrimaryArg());
     }
     PT_HIP_CHECK(hipGetLastError());
     return pt_lanes_join(ctx);   // the hit records are ordered on the caller's stream
@@ -561,9 +588,10 @@ int pt_trace(PtContext* ctx, const PtTlas* tlas, const float camera[32], uint32_
     if (chunk_pixels > n_pixels) chunk_pixels = n_pixels;
     PT_REQUIRE(chunk_pixels * spp < (1ull << 31), "max_paths too large");
     const PtTlasView tv = view_of(tlas);
-    PtCameraArg cam_arg;
-    memcpy(cam_arg.m, camera, sizeof cam_arg.m);
-    const int blocks_i = persistent_blocks(ctx, (const void*)k_intersect<false>);
+    PtPrimaryArg primary;
+    memcpy(primary.camera.m, camera, sizeof primary.camera.m);
+    primary.spp = spp; primary.W = width; primary.H = height; primary.frame = frame; primary.seed_mode = seed_mode;
+    const int blocks_i = persistent_blocks(ctx, (const void*)k_intersect<false, false>);
     // Every chunk of the frame goes to the next lane and is left in flight there; only the
     // read-modify-write of the image is chained, in submission order.
     for (uint64_t p0 = 0; p0 < n_pixels; p0 += chunk_pixels) {
@@ -577,8 +605,8 @@ int pt_trace(PtContext* ctx, const PtTlas* tlas, const float camera[32], uint32_
         // one wave per batch of the fullest shard at bounce 0
         const uint32_t blocks_flat = (uint32_t)((((uint64_t)n_paths + 63) / 64 + kShards - 1) / kShards * kShards + kBlock / 64 - 1) / (kBlock / 64);
         PT_HIP_CHECK(hipMemsetAsync(w.counters, 0, sizeof(uint32_t) * kCounterWords, st));
-        k_generate<<<(n_paths + kBlock - 1) / kBlock, kBlock, 0, st>>>(n_paths, (uint32_t)p0, spp, width, height, frame, seed_mode, w.shard_cap,
-                                                                      cam_arg, w.q[0][0], w.q[0][1], w.counters);
+        primary.n_paths = n_paths; primary.pixel0 = (uint32_t)p0;
+        k_init_counts<<<1, 64, 0, st>>>(n_paths, w.counters);
         for (uint32_t d = 0; d < max_depth; ++d) {
             const int a = d & 1, b = a ^ 1;
             hipEvent_t ev_stop = nullptr;
@@ -592,11 +620,15 @@ int pt_trace(PtContext* ctx, const PtTlas* tlas, const float camera[32], uint32_
                 ev_stop = ctx->ev_pool[ctx->ev_used + 1];
                 ctx->ev_used += 2;
             }
-            k_intersect<false><<<blocks_i, kBlock, 0, st>>>(tv, w.counters, d, w.shard_cap, w.q[a][0], w.q[a][1],
-                                                            0.001f, 10000.0f, w.hits, nullptr, w.spill, sched_threshold(ctx, d));
+            if (d == 0)
+                k_intersect<false, true><<<blocks_i, kBlock, 0, st>>>(tv, w.counters, d, w.shard_cap, w.q[a][0], w.q[a][1],
+                                                                      0.001f, 10000.0f, w.hits, nullptr, w.spill, 0xFFFFFFFFu, primary);
+            else
+                k_intersect<false, false><<<blocks_i, kBlock, 0, st>>>(tv, w.counters, d, w.shard_cap, w.q[a][0], w.q[a][1],
+                                                                       0.001f, 10000.0f, w.hits, nullptr, w.spill, sched_threshold(ctx, d), primary);
             if (ev_stop) PT_HIP_CHECK(hipEventRecord(ev_stop, st));
 #define PT_SHADE_ARGS tlas->shade_inst, d, max_depth, w.counters, w.shard_cap, w.hits, w.q[a][0], w.q[a][1], w.q[a][2], w.q[a][3], \
-                      w.q[b][0], w.q[b][1], w.q[b][2], w.q[b][3], w.path_result
+                      w.q[b][0], w.q[b][1], w.q[b][2], w.q[b][3], w.path_result, primary
             if (d == 0) k_shade<true><<<blocks_flat, kBlock, 0, st>>>(PT_SHADE_ARGS);
             else k_shade<false><<<blocks_flat, kBlock, 0, st>>>(PT_SHADE_ARGS);
 #undef PT_SHADE_ARGS
