@@ -128,15 +128,15 @@ __device__ __forceinline__ void pt_primary_ray(const PtPrimaryArg& P, uint32_t q
     ox = VI[12]; oy = VI[13]; oz = VI[14];
 }
 
-// ray_gen.rgen:38-40 (per-sample seed) and the slot of the path's final radiance, [sample][pixel of the
-// chunk] so that the per-pixel sum reads consecutive pixels together
+// ray_gen.rgen:38-40 (per-sample seed) and the slot of the path's final radiance, [pixel of the chunk][sample]:
+// the samples of a pixel sit in neighbouring lanes when their paths end, so they are written together
 __device__ __forceinline__ void pt_primary_seed(const PtPrimaryArg& P, uint32_t q, uint32_t& seed, uint32_t& result_slot)
 {
     const uint32_t in_chunk = q / P.spp, s = q % P.spp, pixel = P.pixel0 + in_chunk;
     const uint32_t px = pixel % P.W, py = pixel / P.W;
     const uint32_t v1 = P.seed_mode == PT_SEED_CLOCK ? (uint32_t)clock64() : P.frame * P.spp + s;
     seed = pt_tea(py * P.W + px, v1);
-    result_slot = s * (P.n_paths / P.spp) + in_chunk;
+    result_slot = q;
 }
 
 __global__ void k_init_counts(uint32_t n_paths, uint32_t* __restrict__ counters)
@@ -382,8 +382,19 @@ k_accumulate(uint32_t n_pixels, uint32_t pixel0, uint32_t spp, uint32_t frame, u
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_pixels) return;
     float r = 0.0f, g = 0.0f, b = 0.0f;
-    for (uint32_t s = 0; s < spp; ++s) {
-        const float4 hv = path_result[(size_t)s * n_pixels + p];
+    // a pixel's samples are consecutive: eight 16-byte loads (one 128-byte line) are issued together,
+    // so the line is fetched once however many waves share the L1; the sum keeps the sample order
+    const float4* __restrict__ mine = path_result + (size_t)p * spp;
+    uint32_t s = 0;
+    for (; s + 8 <= spp; s += 8) {
+        float4 hv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) hv[k] = mine[s + k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { r = PT_FMA(hv[k].x, 2.5f, r); g = PT_FMA(hv[k].y, 2.5f, g); b = PT_FMA(hv[k].z, 2.5f, b); }
+    }
+    for (; s < spp; ++s) {
+        const float4 hv = mine[s];
         r = PT_FMA(hv.x, 2.5f, r); g = PT_FMA(hv.y, 2.5f, g); b = PT_FMA(hv.z, 2.5f, b);
     }
     const float fs = (float)spp;

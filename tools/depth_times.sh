@@ -13,11 +13,13 @@ rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
 frames, cur = [], None
 for r in rows:
     n = r['Kernel_Name']; d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
-    if 'k_generate' in n: cur = {'I': [], 'S': []}; frames.append(cur)
+    if 'k_init_counts' in n: cur = {'I': [], 'S': [], 't0': int(r['Start_Timestamp'])}; frames.append(cur)
     elif cur is not None and 'k_intersect' in n: cur['I'].append(d)
     elif cur is not None and 'k_shade' in n: cur['S'].append(d)
+    if cur is not None: cur['t1'] = int(r['End_Timestamp'])
 fr = frames[-4:]
 for k in 'IS':
     per = [round(sum(f[k][d] for f in fr) / len(fr)) for d in range(len(fr[0][k]))]
     print(sys.argv[1], k, per, 'sum', sum(per))
+print(sys.argv[1], 'frame span us', [round((f['t1'] - f['t0']) / 1e3) for f in fr])
 PY

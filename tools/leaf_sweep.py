@@ -10,7 +10,7 @@ from pt_amd import hip, procedural
 
 scene = procedural.dragon_standin()
 W, H, SPP = 1920, 1080, 64
-for max_leaf in (1, 2, 3, 4, 6, 8):
+for max_leaf in [int(x) for x in os.environ.get("LEAVES", "1,2,3,4,6,8").split(",")]:
     r = hip.Renderer(scene, W, H, max_leaf=max_leaf)
     for f in range(3):
         r.render(spp=SPP, max_depth=10, frame=f)
