@@ -262,9 +262,11 @@ k_shade(const PtDevShadeInstance* __restrict__ shade_inst, uint32_t depth, uint3
             const PtHit h = hits[i];
             uint32_t seed_in, path;
             if (FIRST) pt_primary_seed(primary, path_of_slot(i, shard, shard_cap), seed_in, path);
-            else { seed_in = __float_as_uint(q0[i].w); path = __float_as_uint(q1[i].w); }
+            // the incoming ray is not needed here: the seed and the result slot travel in the spare
+            // words of the weight and radiance streams, so shading reads three streams, not five
             const float4 cw = FIRST ? make_float4(1.0f, 1.0f, 1.0f, 0.0f) : q2[i];
             float4 hv = FIRST ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : q3[i];
+            if (!FIRST) { seed_in = __float_as_uint(cw.w); path = __float_as_uint(hv.w); }
             if (h.instance == 0xFFFFFFFFu) {
                 // miss.rmiss:10-20
                 const float e = depth == 0 ? 1.0f * 0.8f : 0.01f;
@@ -349,10 +351,10 @@ k_shade(const PtDevShadeInstance* __restrict__ shade_inst, uint32_t depth, uint3
                 hv.z = PT_FMA(em.z, cw.z, hv.z);
                 if (depth + 1 < max_depth) {
                     alive = true;
-                    no = make_float4(wx, wy, wz, __uint_as_float(seed));
-                    nd = make_float4(Dx, Dy, Dz, __uint_as_float(path));
-                    nw = make_float4(cw.x * wr, cw.y * wg, cw.z * wb, 0.0f);
-                    nh = hv;
+                    no = make_float4(wx, wy, wz, 0.0f);
+                    nd = make_float4(Dx, Dy, Dz, 0.0f);
+                    nw = make_float4(cw.x * wr, cw.y * wg, cw.z * wb, __uint_as_float(seed));
+                    nh = make_float4(hv.x, hv.y, hv.z, __uint_as_float(path));
                 } else {
                     path_result[path] = hv;
                 }
