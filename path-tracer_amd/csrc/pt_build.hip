@@ -1061,9 +1061,20 @@ int pt_tlas_build(PtContext* ctx, const PtInstance* instances, uint32_t n, PtTla
         if (e != hipSuccess) { pt_set_error("pt_tlas_build: %s", hipGetErrorString(e)); pt_tlas_destroy(t); return PT_ERROR_HIP; }
         t->pool_node_count = total_nodes;
     }
-    e = hipMalloc((void**)&t->inst, sizeof(PtDevInstance) * n);
+    // instance records in the order of the TLAS leaves, so a leaf reference addresses its record
+    // directly; the instance's own index (the tie-break key and what a hit reports) sits in q[5].y
+    std::vector<uint32_t> slot_inst(n);
+    std::vector<PtDevInstance> di_sorted(n);
+    e = hipMemcpy(slot_inst.data(), t->leaf_inst, sizeof(uint32_t) * n, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) {
+        for (uint32_t k = 0; k < n; ++k) {
+            di_sorted[k] = di[slot_inst[k]];
+            float f; memcpy(&f, &slot_inst[k], 4); di_sorted[k].q[5].y = f;
+        }
+        e = hipMalloc((void**)&t->inst, sizeof(PtDevInstance) * n);
+    }
     if (e == hipSuccess) e = hipMalloc((void**)&t->shade_inst, sizeof(PtDevShadeInstance) * n);
-    if (e == hipSuccess) e = hipMemcpyAsync(t->inst, di.data(), sizeof(PtDevInstance) * n, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(t->inst, di_sorted.data(), sizeof(PtDevInstance) * n, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipEventRecord(ev1, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) { pt_set_error("pt_tlas_build: %s", hipGetErrorString(e)); pt_tlas_destroy(t); return PT_ERROR_HIP; }

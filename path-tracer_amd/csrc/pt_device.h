@@ -115,8 +115,7 @@ __device__ __forceinline__ void pt_hit_update(PtHitRec& best, float t, uint32_t 
 struct PtTlasView {
     const float4* nodes;
     const float4* tris;
-    const uint32_t* leaf_inst;
-    const PtDevInstance* inst;
+    const PtDevInstance* inst;     // in the order of the TLAS leaf slots
 };
 
 #define PT_NODE_SENTINEL 0x7FFFFFFF
@@ -129,6 +128,7 @@ struct PtTlasView {
 // run with PT_TRAVERSE_BLOCK threads per block, which makes the LDS stride a constant.
 #define PT_TRAVERSE_BLOCK 256
 typedef __attribute__((address_space(3))) int pt_lds_int;
+typedef __attribute__((address_space(3))) float pt_lds_float;
 
 struct PtStack {
     pt_lds_int* lds;   // &s_stack[0][threadIdx.x]
@@ -216,11 +216,10 @@ __device__ __forceinline__ int pt_wide_step(const PtRaySpace& r, const float4* _
     return tn[0] < inf ? ref[0] : stk.pop();
 }
 
-// Moves a world-space ray into the object space of instance record q (world->object rows q[0..2]).
-__device__ __forceinline__ void pt_to_object_space(const float4* __restrict__ q, const PtRaySpace& ws,
+// Moves a world-space ray into the object space of an instance (world->object rows r0..r2).
+__device__ __forceinline__ void pt_to_object_space(const float4 r0, const float4 r1, const float4 r2, const PtRaySpace& ws,
                                                    float& ox, float& oy, float& oz, float& dx, float& dy, float& dz)
 {
-    const float4 r0 = q[0], r1 = q[1], r2 = q[2];
     ox = PT_FMA(r0.x, ws.ox, PT_FMA(r0.y, ws.oy, PT_FMA(r0.z, ws.oz, r0.w)));
     oy = PT_FMA(r1.x, ws.ox, PT_FMA(r1.y, ws.oy, PT_FMA(r1.z, ws.oz, r1.w)));
     oz = PT_FMA(r2.x, ws.ox, PT_FMA(r2.y, ws.oy, PT_FMA(r2.z, ws.oz, r2.w)));
@@ -259,14 +258,14 @@ __device__ __forceinline__ void pt_closest_hit(const PtTlasView& tl, PtStack& st
         const uint32_t code = ~(uint32_t)node;
         const uint32_t first = code >> 3, cnt = (code & 7u) + 1u;
         if (cur_inst == PT_NO_INSTANCE) {
-            const uint32_t ii = tl.leaf_inst[first];
-            const float4* q = tl.inst[ii].q;
+            const float4* q = tl.inst[first].q;
             const float4 blo = q[3], bhi = q[4];
+            const uint32_t ii = __float_as_uint(q[5].y);
             float a, b;
             pt_slab(ws, blo.x, blo.y, blo.z, bhi.x, bhi.y, bhi.z, a, b);
             if ((a <= b) && !(b < tmin) && !(a > tmax) && !(a > best.t)) {
                 float oox, ooy, ooz, odx, ody, odz;
-                pt_to_object_space(q, ws, oox, ooy, ooz, odx, ody, odz);
+                pt_to_object_space(q[0], q[1], q[2], ws, oox, ooy, ooz, odx, ody, odz);
                 if (pt_ray_valid(odx, ody, odz)) {
                     pt_ray_space_init(cur, oox, ooy, ooz, odx, ody, odz);
                     delta = blo.w;

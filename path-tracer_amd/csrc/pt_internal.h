@@ -31,7 +31,8 @@ void pt_set_error(const char* fmt, ...);
 // ---- device-side records -------------------------------------------------------------------
 // Traversal view of one TLAS instance: six float4.
 //   [0..2] world->object rows; [3] = (box lo.xyz, delta); [4] = (box hi.xyz, bits(custom index));
-//   [5] = (bits(root node index of the BLAS inside the TLAS pool), -, -, -)
+//   [5] = (bits(root node index of the BLAS inside the TLAS pool), bits(instance index), -, -)
+// The TLAS keeps them in the order of its leaves: record k belongs to leaf slot k.
 struct PtDevInstance { float4 q[6]; };
 // Shading view of one instance: the bindless chain blasInstances[custom] -> geometryNodes[first + 0] ->
 // materials[materialIndex] -> textures[albedoMapIndex] (closest_hit.rchit:57-59,75-79) is constant per
@@ -73,7 +74,7 @@ struct PtTlas {
     uint32_t pool_node_count;
     uint32_t wide_count, wide_depth;  // the TLAS's own wide nodes: the first wide_count of the pool
     uint32_t* leaf_inst;            // device, instance index per sorted slot
-    PtDevInstance* inst;            // device, n
+    PtDevInstance* inst;            // device, n, in leaf-slot order
     PtDevShadeInstance* shade_inst; // device, n; rebuilt when the context's tables change
     uint64_t shade_version;         // ctx->tables_version the records were built from
     std::vector<float> host_o2w;    // n x 12

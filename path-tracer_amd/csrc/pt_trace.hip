@@ -163,6 +163,7 @@ k_intersect(PtTlasView tl, uint32_t* __restrict__ counters, uint32_t depth, uint
             PtPrimaryArg primary)
 {
     __shared__ int s_stack[PT_LDS_STACK][kBlock];
+    __shared__ float s_world[12][kBlock];   // scheduled traversal: the world-space ray of a lane inside an instance
     PtStack stk;
     stk.lds = (pt_lds_int*)&s_stack[0][threadIdx.x];
     stk.spill_base = spill;
@@ -172,7 +173,7 @@ k_intersect(PtTlasView tl, uint32_t* __restrict__ counters, uint32_t depth, uint
         PtSchedQueue Q;
         Q.counters = counters; Q.shard_cap = shard_cap; Q.n_shards = kShards; Q.ctr_pad = kCtrPad;
         Q.count_base = ctr_index(CTR_COUNT, depth, 0); Q.work_base = ctr_index(CTR_WORK_INTERSECT, depth, 0);
-        pt_traverse_sched<BY_ID>(tl, Q, stk, q0, q1, tmin, tmax, hits, t_out);
+        pt_traverse_sched<BY_ID>(tl, Q, stk, (pt_lds_float*)&s_world[0][threadIdx.x], q0, q1, tmin, tmax, hits, t_out);
         return;
     }
     for_each_batch<false>(counters, CTR_WORK_INTERSECT, depth, shard_cap, [&](uint32_t i, bool valid, uint32_t shard) {
@@ -549,7 +550,7 @@ uint32_t sched_threshold(const PtContext* ctx, uint32_t depth)
 PtTlasView view_of(const PtTlas* t)
 {
     PtTlasView v;
-    v.nodes = (const float4*)t->pool_nodes; v.tris = t->pool_tris; v.leaf_inst = t->leaf_inst; v.inst = t->inst;
+    v.nodes = (const float4*)t->pool_nodes; v.tris = t->pool_tris; v.inst = t->inst;
     return v;
 }
 

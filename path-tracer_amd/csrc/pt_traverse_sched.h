@@ -13,9 +13,9 @@
 // (b) phase voting: the wave executes ONE phase at a time -- the one its lanes vote for, for a few
 //     steps in a row -- and the other lanes wait, so the long phases (triangle test, instance entry)
 //     only run once enough lanes have accumulated in them.
-// Per-lane state is kept small (one ray space, the best hit, six scalars): the world-space ray is
-// re-read from the queue when a lane leaves an instance, and the triangle test rebuilds its axis
-// permutation from the ray, which keeps the kernel within the 128 registers of four waves per SIMD
+// Per-lane state is kept small (one ray space, the best hit, six scalars): the world-space ray waits
+// in LDS (ws: 12 words per lane, [word][thread]) while a lane is inside an instance, and the triangle
+// test rebuilds its axis permutation from the ray, which keeps the kernel within the 128 registers of four waves per SIMD
 // without spills.
 // The per-lane arithmetic (slab test, gated watertight triangle test, hit ordering) is the one in
 // pt_device.h, so results are bit-identical to the plain traversal.
@@ -58,7 +58,7 @@ struct PtSchedQueue {              // the sharded queue of one bounce
 };
 
 template <bool BY_ID>
-__device__ __forceinline__ void pt_traverse_sched(const PtTlasView& tl, const PtSchedQueue& Q, PtStack& stk,
+__device__ __forceinline__ void pt_traverse_sched(const PtTlasView& tl, const PtSchedQueue& Q, PtStack& stk, pt_lds_float* ws,
                                                   const float4* __restrict__ q0, const float4* __restrict__ q1,
                                                   float tmin, float tmax, PtHit* __restrict__ hits, float* __restrict__ t_out)
 {
@@ -95,8 +95,13 @@ __device__ __forceinline__ void pt_traverse_sched(const PtTlasView& tl, const Pt
     auto advance = [&](int v) {
         for (;;) {
             if (v == PT_NODE_SENTINEL) {
-                const float4 o = q0[qi], d = q1[qi];
-                pt_ray_space_init(cur, o.x, o.y, o.z, d.x, d.y, d.z);
+                // nothing left above the instance: the ray is finished, its world-space form is not needed
+                if (stk.sp == 0) { v = PT_NODE_DONE; continue; }
+                // a few lanes at a time get here, so this must not wait for global memory or divide
+                cur.ox = ws[0 * PT_TRAVERSE_BLOCK]; cur.oy = ws[1 * PT_TRAVERSE_BLOCK]; cur.oz = ws[2 * PT_TRAVERSE_BLOCK];
+                cur.dx = ws[3 * PT_TRAVERSE_BLOCK]; cur.dy = ws[4 * PT_TRAVERSE_BLOCK]; cur.dz = ws[5 * PT_TRAVERSE_BLOCK];
+                cur.ix = ws[6 * PT_TRAVERSE_BLOCK]; cur.iy = ws[7 * PT_TRAVERSE_BLOCK]; cur.iz = ws[8 * PT_TRAVERSE_BLOCK];
+                cur.oox = ws[9 * PT_TRAVERSE_BLOCK]; cur.ooy = ws[10 * PT_TRAVERSE_BLOCK]; cur.ooz = ws[11 * PT_TRAVERSE_BLOCK];
                 cur_inst = PT_NO_INSTANCE; tlo = tmin; thi = tmax;
                 v = stk.pop();
                 continue;
@@ -146,6 +151,10 @@ __device__ __forceinline__ void pt_traverse_sched(const PtTlasView& tl, const Pt
                     qi = wcur + rank;
                     const float4 o = q0[qi], d = q1[qi];
                     pt_ray_space_init(cur, o.x, o.y, o.z, d.x, d.y, d.z);
+                    ws[0 * PT_TRAVERSE_BLOCK] = cur.ox; ws[1 * PT_TRAVERSE_BLOCK] = cur.oy; ws[2 * PT_TRAVERSE_BLOCK] = cur.oz;
+                    ws[3 * PT_TRAVERSE_BLOCK] = cur.dx; ws[4 * PT_TRAVERSE_BLOCK] = cur.dy; ws[5 * PT_TRAVERSE_BLOCK] = cur.dz;
+                    ws[6 * PT_TRAVERSE_BLOCK] = cur.ix; ws[7 * PT_TRAVERSE_BLOCK] = cur.iy; ws[8 * PT_TRAVERSE_BLOCK] = cur.iz;
+                    ws[9 * PT_TRAVERSE_BLOCK] = cur.oox; ws[10 * PT_TRAVERSE_BLOCK] = cur.ooy; ws[11 * PT_TRAVERSE_BLOCK] = cur.ooz;
                     cur_inst = PT_NO_INSTANCE; tlo = tmin; thi = tmax;
                     best.t = tmax; best.inst = PT_NO_INSTANCE; best.prim = 0xFFFFFFFFu; best.u = best.v = 0.0f;
                     stk.sp = 0;
@@ -208,23 +217,23 @@ __device__ __forceinline__ void pt_traverse_sched(const PtTlasView& tl, const Pt
         } else {
             PT_STAT(2, 1); PT_STAT(5, n_enter);
             if (want_enter) {
-                const uint32_t ii = tl.leaf_inst[(~(uint32_t)node) >> 3];
-                const float4* q = tl.inst[ii].q;
-                const float4 blo = q[3], bhi = q[4];
+                // the whole record is requested at once: one round trip, not one per use
+                const float4* q = tl.inst[(~(uint32_t)node) >> 3].q;
+                const float4 r0 = q[0], r1 = q[1], r2 = q[2], blo = q[3], bhi = q[4], misc = q[5];
                 float a, b;
                 pt_slab(cur, blo.x, blo.y, blo.z, bhi.x, bhi.y, bhi.z, a, b);
                 bool enter = (a <= b) && !(b < tmin) && !(a > tmax) && !(a > best.t);
                 if (enter) {
                     float oox, ooy, ooz, odx, ody, odz;
-                    pt_to_object_space(q, cur, oox, ooy, ooz, odx, ody, odz);
+                    pt_to_object_space(r0, r1, r2, cur, oox, ooy, ooz, odx, ody, odz);
                     enter = pt_ray_valid(odx, ody, odz);
                     if (enter) {
                         pt_ray_space_init(cur, oox, ooy, ooz, odx, ody, odz);
                         delta = blo.w;
-                        cur_inst = ii;
+                        cur_inst = __float_as_uint(misc.y);
                         tlo = fmaxf(tmin, a); thi = fminf(tmax, b);
                         stk.push(PT_NODE_SENTINEL);
-                        node = __float_as_int(q[5].x);
+                        node = __float_as_int(misc.x);
                     }
                 }
                 if (!enter) advance(stk.pop());
