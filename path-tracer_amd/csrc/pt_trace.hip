@@ -154,13 +154,11 @@ __global__ void k_init_counts(uint32_t n_paths, uint32_t* __restrict__ counters)
 // The level's size lives on the device, so the kernel decides: scheduled when the level holds at
 // least sched_min_rays rays (0 forces it, UINT32_MAX forces the plain schedule).
 // BY_ID: hit records go to hits[path id] (pt_intersect: caller's ray order) instead of the queue slot.
-// FIRST: bounce 0 of pt_trace; rays are computed from the path index (plain schedule, they are coherent).
-template <bool BY_ID, bool FIRST>
+template <bool BY_ID>
 __global__ void __launch_bounds__(kBlock, PT_INTERSECT_WAVES)
 k_intersect(PtTlasView tl, uint32_t* __restrict__ counters, uint32_t depth, uint32_t shard_cap,
             const float4* __restrict__ q0, const float4* __restrict__ q1, float tmin, float tmax,
-            PtHit* __restrict__ hits, float* __restrict__ t_out, int* __restrict__ spill, uint32_t sched_min_rays,
-            PtPrimaryArg primary)
+            PtHit* __restrict__ hits, float* __restrict__ t_out, int* __restrict__ spill, uint32_t sched_min_rays)
 {
     __shared__ int s_stack[PT_LDS_STACK][kBlock];
     __shared__ float s_world[12][kBlock];   // scheduled traversal: the world-space ray of a lane inside an instance
@@ -169,7 +167,7 @@ k_intersect(PtTlasView tl, uint32_t* __restrict__ counters, uint32_t depth, uint
     stk.spill_base = spill;
     uint32_t total = counters[ctr_index(CTR_COUNT, depth, threadIdx.x & (kShards - 1))];   // lane s: shard s
     for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off);
-    if (!FIRST && total >= sched_min_rays) {
+    if (total >= sched_min_rays) {
         PtSchedQueue Q;
         Q.counters = counters; Q.shard_cap = shard_cap; Q.n_shards = kShards; Q.ctr_pad = kCtrPad;
         Q.count_base = ctr_index(CTR_COUNT, depth, 0); Q.work_base = ctr_index(CTR_WORK_INTERSECT, depth, 0);
@@ -178,9 +176,7 @@ k_intersect(PtTlasView tl, uint32_t* __restrict__ counters, uint32_t depth, uint
     }
     for_each_batch<false>(counters, CTR_WORK_INTERSECT, depth, shard_cap, [&](uint32_t i, bool valid, uint32_t shard) {
         if (valid) {
-            float4 o, d;
-            if (FIRST) { pt_primary_ray(primary, path_of_slot(i, shard, shard_cap), o.x, o.y, o.z, d.x, d.y, d.z); d.w = 0.0f; }
-            else { o = q0[i]; d = q1[i]; }
+            const float4 o = q0[i], d = q1[i];
             PtHitRec h;
             pt_closest_hit(tl, stk, o.x, o.y, o.z, d.x, d.y, d.z, tmin, tmax, h);
             PtHit out; out.instance = h.inst; out.primitive = h.prim; out.u = h.u; out.v = h.v;
@@ -238,7 +234,147 @@ __device__ __forceinline__ void pt_texture_rgb(const uint32_t* __restrict__ texe
     r = out[0]; g = out[1]; b = out[2];
 }
 
+// What closest_hit.rchit / miss.rmiss need besides the hit: the streams of the level being shaded
+// (q2 weight + seed, q3 radiance + result slot), the next level's queue (o0..o3) and the results.
+struct PtShadeArgs {
+    const PtDevShadeInstance* shade_inst;
+    uint32_t depth, max_depth;
+    uint32_t* counters;
+    uint32_t shard_cap;
+    const float4 *q2, *q3;
+    float4 *o0, *o1, *o2, *o3;
+    float4* path_result;
+    PtPrimaryArg primary;
+};
+
+// Shades the 64 slots of one batch (slot i per lane, hit h) and compacts the surviving paths into the
+// same shard of the next queue.  Called by every lane of the wave, valid or not.
 // FIRST: bounce 0, where the path weight is 1 and the collected radiance 0 and neither is read.
+template <bool FIRST>
+__device__ __forceinline__ void shade_batch(const PtShadeArgs& S, const PtDevShadeInstance* __restrict__ shade_inst,
+                                            const float4* __restrict__ q2, const float4* __restrict__ q3,
+                                            float4* __restrict__ o0, float4* __restrict__ o1, float4* __restrict__ o2, float4* __restrict__ o3,
+                                            float4* __restrict__ path_result, uint32_t i, bool valid, uint32_t shard, const PtHit h)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const float PI_F = 3.14159265f;
+    bool alive = false;
+    float4 no, nd, nw, nh;
+    if (valid) {
+        uint32_t seed_in, path;
+        if (FIRST) pt_primary_seed(S.primary, path_of_slot(i, shard, S.shard_cap), seed_in, path);
+        // the incoming ray is not needed here: the seed and the result slot travel in the spare
+        // words of the weight and radiance streams, so shading reads three streams, not five
+        const float4 cw = FIRST ? make_float4(1.0f, 1.0f, 1.0f, 0.0f) : q2[i];
+        float4 hv = FIRST ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : q3[i];
+        if (!FIRST) { seed_in = __float_as_uint(cw.w); path = __float_as_uint(hv.w); }
+        if (h.instance == 0xFFFFFFFFu) {
+            // miss.rmiss:10-20
+            const float e = S.depth == 0 ? 1.0f * 0.8f : 0.01f;
+            hv.x = PT_FMA(e, cw.x, hv.x); hv.y = PT_FMA(e, cw.y, hv.y); hv.z = PT_FMA(e, cw.z, hv.z);
+            path_result[path] = hv;
+        } else {
+            // closest_hit.rchit:57-60 (table chain pre-resolved per instance)
+            const PtDevShadeInstance& I = shade_inst[h.instance];
+            const float4 ptrs = I.ptrs;
+            const PtVertex* vertices = (const PtVertex*)ptr_from(ptrs.x, ptrs.y);
+            const uint32_t* indices = (const uint32_t*)ptr_from(ptrs.z, ptrs.w);
+            const uint32_t ia = indices[3 * (size_t)h.primitive + 0], ib = indices[3 * (size_t)h.primitive + 1], ic = indices[3 * (size_t)h.primitive + 2];
+            PtVertex A, B, C;
+            if ((((uintptr_t)vertices) & 15u) == 0) {
+                // 32-byte vertices on a 16-byte boundary: two 16-byte loads each instead of eight dwords
+                const float4* v4 = (const float4*)vertices;
+                const float4 a0 = v4[2 * (size_t)ia], a1 = v4[2 * (size_t)ia + 1];
+                const float4 b0_ = v4[2 * (size_t)ib], b1_ = v4[2 * (size_t)ib + 1];
+                const float4 c0 = v4[2 * (size_t)ic], c1 = v4[2 * (size_t)ic + 1];
+                A = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
+                B = { b0_.x, b0_.y, b0_.z, b0_.w, b1_.x, b1_.y, b1_.z, b1_.w };
+                C = { c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w };
+            } else {
+                A = vertices[ia]; B = vertices[ib]; C = vertices[ic];
+            }
+            const float b0 = 1.0f - h.u - h.v, b1 = h.u, b2 = h.v;
+#define PT_MIX3(x, y, z) PT_FMA((z), b2, PT_FMA((y), b1, (x) * b0))
+            float px = PT_MIX3(A.px, B.px, C.px), py = PT_MIX3(A.py, B.py, C.py), pz = PT_MIX3(A.pz, B.pz, C.pz);
+            float nx = PT_MIX3(A.nx, B.nx, C.nx), ny = PT_MIX3(A.ny, B.ny, C.ny), nz = PT_MIX3(A.nz, B.nz, C.nz);
+            float tu = PT_MIX3(A.tu, B.tu, C.tu), tv = PT_MIX3(A.tv, B.tv, C.tv);
+#undef PT_MIX3
+            pt_normalize(nx, ny, nz);
+            // :62-63
+            const float4 m0 = I.o2w[0], m1 = I.o2w[1], m2 = I.o2w[2];
+            float wx = PT_FMA(m0.x, px, PT_FMA(m0.y, py, PT_FMA(m0.z, pz, m0.w)));
+            float wy = PT_FMA(m1.x, px, PT_FMA(m1.y, py, PT_FMA(m1.z, pz, m1.w)));
+            float wz = PT_FMA(m2.x, px, PT_FMA(m2.y, py, PT_FMA(m2.z, pz, m2.w)));
+            const float4 w0 = I.w2o[0], w1 = I.w2o[1], w2 = I.w2o[2];
+            float Nx = PT_FMA(w0.x, nx, PT_FMA(w1.x, ny, w2.x * nz));
+            float Ny = PT_FMA(w0.y, nx, PT_FMA(w1.y, ny, w2.y * nz));
+            float Nz = PT_FMA(w0.z, nx, PT_FMA(w1.z, ny, w2.z * nz));
+            pt_normalize(Nx, Ny, Nz);
+            // CreateCoordinateSystem, sampling.glsl:53-65
+            float Tx, Ty, Tz;
+            if (fabsf(Nx) > fabsf(Ny)) {
+                float inv = 1.0f / sqrtf(PT_FMA(Nz, Nz, Nx * Nx));
+                Tx = Nz * inv; Ty = 0.0f; Tz = -Nx * inv;
+            } else {
+                float inv = 1.0f / sqrtf(PT_FMA(Nz, Nz, Ny * Ny));
+                Tx = 0.0f; Ty = -Nz * inv; Tz = Ny * inv;
+            }
+            float Bx = PT_FMA(Ny, Tz, -(Nz * Ty));
+            float By = PT_FMA(Nz, Tx, -(Nx * Tz));
+            float Bz = PT_FMA(Nx, Ty, -(Ny * Tx));
+            // SamplingHemisphere, sampling.glsl:38-50
+            uint32_t seed = seed_in;
+            float r1 = pt_random(seed);
+            float r2 = pt_random(seed);
+            float sq = sqrtf(r1);
+            float sn, cs;
+            pt_sincos(6.28318548f * r2, sn, cs);
+            float lx = cs * sq, ly = sn * sq, lz = sqrtf(1.0f - r1);
+            float Dx = PT_FMA(lz, Nx, PT_FMA(ly, Bx, lx * Tx));
+            float Dy = PT_FMA(lz, Ny, PT_FMA(ly, By, lx * Ty));
+            float Dz = PT_FMA(lz, Nz, PT_FMA(ly, Bz, lx * Tz));
+            // :71-85
+            float cosTheta = PT_FMA(Dz, Nz, PT_FMA(Dy, Ny, Dx * Nx));
+            float pdf = cosTheta / PI_F;
+            const float4 alb = I.albedo;
+            float ar = alb.x, ag = alb.y, ab = alb.z;
+            if (__float_as_uint(alb.w)) {
+                const float4 tex = I.tex;
+                float tr, tg, tbb;
+                pt_texture_rgb((const uint32_t*)ptr_from(tex.x, tex.y), (int)__float_as_uint(tex.z), (int)__float_as_uint(tex.w), tu, tv, tr, tg, tbb);
+                ar = ar * tr; ag = ag * tg; ab = ab * tbb;
+            }
+            float wr = (ar / PI_F) * cosTheta / pdf, wg = (ag / PI_F) * cosTheta / pdf, wb = (ab / PI_F) * cosTheta / pdf;
+            // ray_gen.rgen:67-68
+            const float4 em = I.emissive;
+            hv.x = PT_FMA(em.x, cw.x, hv.x);
+            hv.y = PT_FMA(em.y, cw.y, hv.y);
+            hv.z = PT_FMA(em.z, cw.z, hv.z);
+            if (S.depth + 1 < S.max_depth) {
+                alive = true;
+                no = make_float4(wx, wy, wz, 0.0f);
+                nd = make_float4(Dx, Dy, Dz, 0.0f);
+                nw = make_float4(cw.x * wr, cw.y * wg, cw.z * wb, __uint_as_float(seed));
+                nh = make_float4(hv.x, hv.y, hv.z, __uint_as_float(path));
+            } else {
+                path_result[path] = hv;
+            }
+        }
+    }
+    // wave-level compaction into the same shard of the next queue: one atomic per batch
+    const unsigned long long bal = __ballot(alive);
+    const uint32_t cnt = __popcll(bal);
+    if (cnt) {
+        uint32_t slot0 = 0;
+        if (lane == 0) slot0 = atomicAdd(&S.counters[ctr_index(CTR_COUNT, S.depth + 1, shard)], cnt);
+        slot0 = __builtin_amdgcn_readfirstlane(slot0);
+        if (alive) {
+            const uint32_t slot = shard * S.shard_cap + slot0 + __popcll(bal & ((1ull << lane) - 1ull));
+            o0[slot] = no; o1[slot] = nd; o2[slot] = nw; o3[slot] = nh;
+        }
+    }
+}
+
 // Launched with one wave per batch of the fullest shard rather than as a persistent grid: a shard
 // never holds more than at bounce 0, so the bounce-0 grid covers every level and waves past a
 // shard's end leave at once.  (Claiming batches one atomic at a time cost a persistent shade pass
@@ -246,133 +382,36 @@ __device__ __forceinline__ void pt_texture_rgb(const uint32_t* __restrict__ texe
 #ifndef PT_SHADE_WAVES
 #define PT_SHADE_WAVES 4
 #endif
-template <bool FIRST>
 __global__ void __launch_bounds__(kBlock, PT_SHADE_WAVES)
-k_shade(const PtDevShadeInstance* __restrict__ shade_inst, uint32_t depth, uint32_t max_depth,
-        uint32_t* __restrict__ counters, uint32_t shard_cap, const PtHit* __restrict__ hits,
-        const float4* __restrict__ q0, const float4* __restrict__ q1, const float4* __restrict__ q2, const float4* __restrict__ q3,
-        float4* __restrict__ o0, float4* __restrict__ o1, float4* __restrict__ o2, float4* __restrict__ o3,
-        float4* __restrict__ path_result, PtPrimaryArg primary)
+k_shade(PtShadeArgs A, const PtHit* __restrict__ hits)
 {
-    const uint32_t lane = threadIdx.x & 63;
-    const float PI_F = 3.14159265f;
-    for_each_batch<true>(counters, CTR_COUNT, depth, shard_cap, [&](uint32_t i, bool valid, uint32_t shard) {
-        bool alive = false;
-        float4 no, nd, nw, nh;
+    for_each_batch<true>(A.counters, CTR_COUNT, A.depth, A.shard_cap, [&](uint32_t i, bool valid, uint32_t shard) {
+        PtHit h; h.instance = 0xFFFFFFFFu; h.primitive = 0u; h.u = h.v = 0.0f;
+        if (valid) h = hits[i];
+        shade_batch<false>(A, A.shade_inst, A.q2, A.q3, A.o0, A.o1, A.o2, A.o3, A.path_result, i, valid, shard, h);
+    });
+}
+
+// Bounce 0 in one kernel: the primary ray is computed from the path index, traced with the plain
+// schedule (primary rays are coherent) and shaded where it ends, so no hit record is written and
+// read back, and the shading traffic overlaps the arithmetic of the other waves' traversal.
+__global__ void __launch_bounds__(kBlock, PT_INTERSECT_WAVES)
+k_primary(PtTlasView tl, PtShadeArgs A, float tmin, float tmax, int* __restrict__ spill)
+{
+    __shared__ int s_stack[PT_LDS_STACK][kBlock];
+    PtStack stk;
+    stk.lds = (pt_lds_int*)&s_stack[0][threadIdx.x];
+    stk.spill_base = spill;
+    for_each_batch<false>(A.counters, CTR_WORK_INTERSECT, 0, A.shard_cap, [&](uint32_t i, bool valid, uint32_t shard) {
+        PtHit h; h.instance = 0xFFFFFFFFu; h.primitive = 0u; h.u = h.v = 0.0f;
         if (valid) {
-            const PtHit h = hits[i];
-            uint32_t seed_in, path;
-            if (FIRST) pt_primary_seed(primary, path_of_slot(i, shard, shard_cap), seed_in, path);
-            // the incoming ray is not needed here: the seed and the result slot travel in the spare
-            // words of the weight and radiance streams, so shading reads three streams, not five
-            const float4 cw = FIRST ? make_float4(1.0f, 1.0f, 1.0f, 0.0f) : q2[i];
-            float4 hv = FIRST ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : q3[i];
-            if (!FIRST) { seed_in = __float_as_uint(cw.w); path = __float_as_uint(hv.w); }
-            if (h.instance == 0xFFFFFFFFu) {
-                // miss.rmiss:10-20
-                const float e = depth == 0 ? 1.0f * 0.8f : 0.01f;
-                hv.x = PT_FMA(e, cw.x, hv.x); hv.y = PT_FMA(e, cw.y, hv.y); hv.z = PT_FMA(e, cw.z, hv.z);
-                path_result[path] = hv;
-            } else {
-                // closest_hit.rchit:57-60 (table chain pre-resolved per instance)
-                const PtDevShadeInstance& I = shade_inst[h.instance];
-                const float4 ptrs = I.ptrs;
-                const PtVertex* vertices = (const PtVertex*)ptr_from(ptrs.x, ptrs.y);
-                const uint32_t* indices = (const uint32_t*)ptr_from(ptrs.z, ptrs.w);
-                const uint32_t ia = indices[3 * (size_t)h.primitive + 0], ib = indices[3 * (size_t)h.primitive + 1], ic = indices[3 * (size_t)h.primitive + 2];
-                PtVertex A, B, C;
-                if ((((uintptr_t)vertices) & 15u) == 0) {
-                    // 32-byte vertices on a 16-byte boundary: two 16-byte loads each instead of eight dwords
-                    const float4* v4 = (const float4*)vertices;
-                    const float4 a0 = v4[2 * (size_t)ia], a1 = v4[2 * (size_t)ia + 1];
-                    const float4 b0_ = v4[2 * (size_t)ib], b1_ = v4[2 * (size_t)ib + 1];
-                    const float4 c0 = v4[2 * (size_t)ic], c1 = v4[2 * (size_t)ic + 1];
-                    A = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
-                    B = { b0_.x, b0_.y, b0_.z, b0_.w, b1_.x, b1_.y, b1_.z, b1_.w };
-                    C = { c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w };
-                } else {
-                    A = vertices[ia]; B = vertices[ib]; C = vertices[ic];
-                }
-                const float b0 = 1.0f - h.u - h.v, b1 = h.u, b2 = h.v;
-#define PT_MIX3(x, y, z) PT_FMA((z), b2, PT_FMA((y), b1, (x) * b0))
-                float px = PT_MIX3(A.px, B.px, C.px), py = PT_MIX3(A.py, B.py, C.py), pz = PT_MIX3(A.pz, B.pz, C.pz);
-                float nx = PT_MIX3(A.nx, B.nx, C.nx), ny = PT_MIX3(A.ny, B.ny, C.ny), nz = PT_MIX3(A.nz, B.nz, C.nz);
-                float tu = PT_MIX3(A.tu, B.tu, C.tu), tv = PT_MIX3(A.tv, B.tv, C.tv);
-#undef PT_MIX3
-                pt_normalize(nx, ny, nz);
-                // :62-63
-                const float4 m0 = I.o2w[0], m1 = I.o2w[1], m2 = I.o2w[2];
-                float wx = PT_FMA(m0.x, px, PT_FMA(m0.y, py, PT_FMA(m0.z, pz, m0.w)));
-                float wy = PT_FMA(m1.x, px, PT_FMA(m1.y, py, PT_FMA(m1.z, pz, m1.w)));
-                float wz = PT_FMA(m2.x, px, PT_FMA(m2.y, py, PT_FMA(m2.z, pz, m2.w)));
-                const float4 w0 = I.w2o[0], w1 = I.w2o[1], w2 = I.w2o[2];
-                float Nx = PT_FMA(w0.x, nx, PT_FMA(w1.x, ny, w2.x * nz));
-                float Ny = PT_FMA(w0.y, nx, PT_FMA(w1.y, ny, w2.y * nz));
-                float Nz = PT_FMA(w0.z, nx, PT_FMA(w1.z, ny, w2.z * nz));
-                pt_normalize(Nx, Ny, Nz);
-                // CreateCoordinateSystem, sampling.glsl:53-65
-                float Tx, Ty, Tz;
-                if (fabsf(Nx) > fabsf(Ny)) {
-                    float inv = 1.0f / sqrtf(PT_FMA(Nz, Nz, Nx * Nx));
-                    Tx = Nz * inv; Ty = 0.0f; Tz = -Nx * inv;
-                } else {
-                    float inv = 1.0f / sqrtf(PT_FMA(Nz, Nz, Ny * Ny));
-                    Tx = 0.0f; Ty = -Nz * inv; Tz = Ny * inv;
-                }
-                float Bx = PT_FMA(Ny, Tz, -(Nz * Ty));
-                float By = PT_FMA(Nz, Tx, -(Nx * Tz));
-                float Bz = PT_FMA(Nx, Ty, -(Ny * Tx));
-                // SamplingHemisphere, sampling.glsl:38-50
-                uint32_t seed = seed_in;
-                float r1 = pt_random(seed);
-                float r2 = pt_random(seed);
-                float sq = sqrtf(r1);
-                float sn, cs;
-                pt_sincos(6.28318548f * r2, sn, cs);
-                float lx = cs * sq, ly = sn * sq, lz = sqrtf(1.0f - r1);
-                float Dx = PT_FMA(lz, Nx, PT_FMA(ly, Bx, lx * Tx));
-                float Dy = PT_FMA(lz, Ny, PT_FMA(ly, By, lx * Ty));
-                float Dz = PT_FMA(lz, Nz, PT_FMA(ly, Bz, lx * Tz));
-                // :71-85
-                float cosTheta = PT_FMA(Dz, Nz, PT_FMA(Dy, Ny, Dx * Nx));
-                float pdf = cosTheta / PI_F;
-                const float4 alb = I.albedo;
-                float ar = alb.x, ag = alb.y, ab = alb.z;
-                if (__float_as_uint(alb.w)) {
-                    const float4 tex = I.tex;
-                    float tr, tg, tbb;
-                    pt_texture_rgb((const uint32_t*)ptr_from(tex.x, tex.y), (int)__float_as_uint(tex.z), (int)__float_as_uint(tex.w), tu, tv, tr, tg, tbb);
-                    ar = ar * tr; ag = ag * tg; ab = ab * tbb;
-                }
-                float wr = (ar / PI_F) * cosTheta / pdf, wg = (ag / PI_F) * cosTheta / pdf, wb = (ab / PI_F) * cosTheta / pdf;
-                // ray_gen.rgen:67-68
-                const float4 em = I.emissive;
-                hv.x = PT_FMA(em.x, cw.x, hv.x);
-                hv.y = PT_FMA(em.y, cw.y, hv.y);
-                hv.z = PT_FMA(em.z, cw.z, hv.z);
-                if (depth + 1 < max_depth) {
-                    alive = true;
-                    no = make_float4(wx, wy, wz, 0.0f);
-                    nd = make_float4(Dx, Dy, Dz, 0.0f);
-                    nw = make_float4(cw.x * wr, cw.y * wg, cw.z * wb, __uint_as_float(seed));
-                    nh = make_float4(hv.x, hv.y, hv.z, __uint_as_float(path));
-                } else {
-                    path_result[path] = hv;
-                }
-            }
+            float ox, oy, oz, dx, dy, dz;
+            pt_primary_ray(A.primary, path_of_slot(i, shard, A.shard_cap), ox, oy, oz, dx, dy, dz);
+            PtHitRec r;
+            pt_closest_hit(tl, stk, ox, oy, oz, dx, dy, dz, tmin, tmax, r);
+            h.instance = r.inst; h.primitive = r.prim; h.u = r.u; h.v = r.v;
         }
-        // wave-level compaction into the same shard of the next queue: one atomic per batch
-        const unsigned long long bal = __ballot(alive);
-        const uint32_t cnt = __popcll(bal);
-        if (cnt) {
-            uint32_t slot0 = 0;
-            if (lane == 0) slot0 = atomicAdd(&counters[ctr_index(CTR_COUNT, depth + 1, shard)], cnt);
-            slot0 = __builtin_amdgcn_readfirstlane(slot0);
-            if (alive) {
-                const uint32_t slot = shard * shard_cap + slot0 + __popcll(bal & ((1ull << lane) - 1ull));
-                o0[slot] = no; o1[slot] = nd; o2[slot] = nw; o3[slot] = nh;
-            }
-        }
+        shade_batch<true>(A, A.shade_inst, A.q2, A.q3, A.o0, A.o1, A.o2, A.o3, A.path_result, i, valid, shard, h);
     });
 }
 
@@ -575,9 +614,9 @@ int pt_intersect(PtContext* ctx, const PtTlas* tlas, uint32_t n, const float* or
     k_pack_rays<<<(n + kBlock - 1) / kBlock, kBlock, 0, st>>>(n, w.shard_cap, origins_dev, dirs_dev, w.q[0][0], w.q[0][1], w.counters);
     {
         // caller-supplied rays are treated as incoherent: scheduled above the threshold
-        const int blocks = persistent_blocks(ctx, (const void*)k_intersect<true, false>);
-        k_intersect<true, false><<<blocks, kBlock, 0, st>>>(view_of(tlas), w.counters, 0, w.shard_cap, w.q[0][0], w.q[0][1],
-                                                            tmin, tmax, hits_dev, t_dev, w.spill, sched_threshold(ctx, 1), PtPrimaryArg());
+        const int blocks = persistent_blocks(ctx, (const void*)k_intersect<true>);
+        k_intersect<true><<<blocks, kBlock, 0, st>>>(view_of(tlas), w.counters, 0, w.shard_cap, w.q[0][0], w.q[0][1],
+                                                     tmin, tmax, hits_dev, t_dev, w.spill, sched_threshold(ctx, 1));
     }
     PT_HIP_CHECK(hipGetLastError());
     return pt_lanes_join(ctx);   // the hit records are ordered on the caller's stream
@@ -605,7 +644,8 @@ int pt_trace(PtContext* ctx, const PtTlas* tlas, const float camera[32], uint32_
     PtPrimaryArg primary;
     memcpy(primary.camera.m, camera, sizeof primary.camera.m);
     primary.spp = spp; primary.W = width; primary.H = height; primary.frame = frame; primary.seed_mode = seed_mode;
-    const int blocks_i = persistent_blocks(ctx, (const void*)k_intersect<false, false>);
+    const int blocks_i = persistent_blocks(ctx, (const void*)k_intersect<false>);
+    const int blocks_p = persistent_blocks(ctx, (const void*)k_primary);
     // Every chunk of the frame goes to the next lane and is left in flight there; only the
     // read-modify-write of the image is chained, in submission order.
     for (uint64_t p0 = 0; p0 < n_pixels; p0 += chunk_pixels) {
@@ -634,18 +674,21 @@ int pt_trace(PtContext* ctx, const PtTlas* tlas, const float camera[32], uint32_
                 ev_stop = ctx->ev_pool[ctx->ev_used + 1];
                 ctx->ev_used += 2;
             }
-            if (d == 0)
-                k_intersect<false, true><<<blocks_i, kBlock, 0, st>>>(tv, w.counters, d, w.shard_cap, w.q[a][0], w.q[a][1],
-                                                                      0.001f, 10000.0f, w.hits, nullptr, w.spill, 0xFFFFFFFFu, primary);
-            else
-                k_intersect<false, false><<<blocks_i, kBlock, 0, st>>>(tv, w.counters, d, w.shard_cap, w.q[a][0], w.q[a][1],
-                                                                       0.001f, 10000.0f, w.hits, nullptr, w.spill, sched_threshold(ctx, d), primary);
-            if (ev_stop) PT_HIP_CHECK(hipEventRecord(ev_stop, st));
-#define PT_SHADE_ARGS tlas->shade_inst, d, max_depth, w.counters, w.shard_cap, w.hits, w.q[a][0], w.q[a][1], w.q[a][2], w.q[a][3], \
-                      w.q[b][0], w.q[b][1], w.q[b][2], w.q[b][3], w.path_result, primary
-            if (d == 0) k_shade<true><<<blocks_flat, kBlock, 0, st>>>(PT_SHADE_ARGS);
-            else k_shade<false><<<blocks_flat, kBlock, 0, st>>>(PT_SHADE_ARGS);
-#undef PT_SHADE_ARGS
+            PtShadeArgs sa;
+            sa.shade_inst = tlas->shade_inst; sa.depth = d; sa.max_depth = max_depth; sa.counters = w.counters; sa.shard_cap = w.shard_cap;
+            sa.q2 = w.q[a][2]; sa.q3 = w.q[a][3];
+            sa.o0 = w.q[b][0]; sa.o1 = w.q[b][1]; sa.o2 = w.q[b][2]; sa.o3 = w.q[b][3];
+            sa.path_result = w.path_result; sa.primary = primary;
+            if (d == 0) {
+                // the timed interval of bounce 0 holds its shading as well
+                k_primary<<<blocks_p, kBlock, 0, st>>>(tv, sa, 0.001f, 10000.0f, w.spill);
+                if (ev_stop) PT_HIP_CHECK(hipEventRecord(ev_stop, st));
+            } else {
+                k_intersect<false><<<blocks_i, kBlock, 0, st>>>(tv, w.counters, d, w.shard_cap, w.q[a][0], w.q[a][1],
+                                                                0.001f, 10000.0f, w.hits, nullptr, w.spill, sched_threshold(ctx, d));
+                if (ev_stop) PT_HIP_CHECK(hipEventRecord(ev_stop, st));
+                k_shade<<<blocks_flat, kBlock, 0, st>>>(sa, w.hits);
+            }
         }
         if (ctx->last_accumulate && ctx->last_accumulate != lane)
             PT_HIP_CHECK(hipStreamWaitEvent(st, ctx->last_accumulate->accumulated, 0));

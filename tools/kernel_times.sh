@@ -11,7 +11,7 @@ import csv, glob, sys
 f = glob.glob(sys.argv[2] + '/*/*kernel_stats.csv')[0]
 for r in csv.DictReader(open(f)):
     n = r['Name']
-    if any(k in n for k in ('k_intersect', 'k_shade', 'k_accumulate')):
+    if any(k in n for k in ('k_intersect', 'k_shade', 'k_accumulate', 'k_primary')):
         print('%-6s %-60s calls %4s avg %9.1f us' % (sys.argv[1], n[:60], r['Calls'], float(r['AverageNs']) / 1e3))
 PY
 grep '^{"metric' $out.log | tail -1 | python3 -c "import json,sys; j=json.loads(sys.stdin.read()); print(sys.argv[1], 'ms/step', round(j['ms_per_step'],2), 'rays/s %.3e' % j['value'])" $label
