@@ -966,7 +966,7 @@ int pt_tlas_build(PtContext* ctx, const PtInstance* instances, uint32_t n, PtTla
     t->pool_nodes = nullptr; t->pool_tris = nullptr; t->pool_node_count = 0;
     t->host_boxes.resize((size_t)n * 6); t->host_w2o.resize((size_t)n * 12);
     std::vector<PtDevInstance> di(n);
-    t->host_o2w.resize((size_t)n * 12); t->host_custom.resize(n); t->shade_version = 0;
+    t->host_o2w.resize((size_t)n * 12); t->host_custom.resize(n); t->host_prim_count.resize(n); t->shade_version = 0;
     const float inf = std::numeric_limits<float>::infinity();
     for (int k = 0; k < 3; ++k) { t->root_lo[k] = inf; t->root_hi[k] = -inf; }
     for (uint32_t i = 0; i < n; ++i) {
@@ -1004,6 +1004,7 @@ int pt_tlas_build(PtContext* ctx, const PtInstance* instances, uint32_t n, PtTla
         }
         memcpy(&t->host_o2w[12 * (size_t)i], m, 48);
         t->host_custom[i] = custom;
+        t->host_prim_count[i] = b->prim_count;
         di[i].q[3] = make_float4(lo[0], lo[1], lo[2], b->delta);
         di[i].q[4] = make_float4(hi[0], hi[1], hi[2], customf);
         di[i].q[5] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // x = bits(root node of the BLAS in the pool), set below
@@ -1089,6 +1090,7 @@ int pt_tlas_destroy(PtTlas* t)
     if (!t) return PT_OK;
     (void)pt_lanes_sync(t->ctx);   // frames in flight traverse the pool
     (void)hipFree(t->nodes); (void)hipFree(t->leaf_inst); (void)hipFree(t->inst); (void)hipFree(t->shade_inst);
+    for (auto& r : t->tri_records) (void)hipFree(r.dev);
     (void)hipFree(t->pool_nodes); (void)hipFree(t->pool_tris);
     delete t;
     return PT_OK;

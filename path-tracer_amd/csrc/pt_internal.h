@@ -40,7 +40,7 @@ struct PtDevInstance { float4 q[6]; };
 struct PtDevShadeInstance {
     float4 o2w[3];
     float4 w2o[3];
-    float4 ptrs;      // vertex pointer lo/hi, index pointer lo/hi
+    float4 ptrs;      // pointer lo/hi to the instance's triangle records (three 32-byte vertices per primitive), -, -
     float4 albedo;    // albedoFactor.rgb, bits(useAlbedoMap)
     float4 emissive;  // emissiveFactor.rgb, -
     float4 tex;       // texel pointer lo/hi, bits(width), bits(height)
@@ -79,6 +79,11 @@ struct PtTlas {
     uint64_t shade_version;         // ctx->tables_version the records were built from
     std::vector<float> host_o2w;    // n x 12
     std::vector<uint32_t> host_custom;
+    std::vector<uint32_t> host_prim_count;   // primitives of each instance's BLAS
+    // Shading input per primitive, gathered through the geometry node's own buffers when the tables
+    // are bound: instances with the same buffers share one array.
+    struct TriRecords { uint64_t vertices, indices; uint32_t prims; float4* dev; };
+    std::vector<TriRecords> tri_records;
     std::vector<float> host_boxes;  // n x 6
     std::vector<float> host_w2o;    // n x 12
     float root_lo[3], root_hi[3];

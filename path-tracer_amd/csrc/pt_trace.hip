@@ -25,6 +25,7 @@
 #include "pt_device.h"
 #include "pt_traverse_sched.h"
 #include <string.h>
+#include <algorithm>
 
 namespace {
 
@@ -60,8 +61,8 @@ __device__ __forceinline__ uint32_t shard_count(uint32_t n, uint32_t s)
 }
 
 // Calls body(slot index, valid, shard) for every 64-slot batch of one queue level.
-// FLAT: the grid has one wave per batch of the fullest shard (wave g: shard g % kShards, batch
-// g / kShards) instead of a persistent grid that claims batches; for levels known to be full.
+// FLAT: batches are dealt to the waves of the grid by index (the grid's wave count must be a multiple of
+// kShards) instead of being claimed with atomics; for passes whose batches cost about the same.
 template <bool FLAT, typename Body>
 __device__ __forceinline__ void for_each_batch(uint32_t* __restrict__ counters, int work_kind, uint32_t depth,
                                                uint32_t shard_cap, Body body)
@@ -69,9 +70,15 @@ __device__ __forceinline__ void for_each_batch(uint32_t* __restrict__ counters, 
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (FLAT) {
-        const uint32_t s = wave % kShards, base = (wave / kShards) * 64u;
+        // wave g of the grid serves shard g % kShards and every (grid waves / kShards)-th batch of it,
+        // starting at batch g / kShards: no claiming, and no wave is launched only to find nothing.
+        // The wave index is uniform; said so, the shard's size comes through the scalar cache.
+        const uint32_t uw = __builtin_amdgcn_readfirstlane(wave);
+        const uint32_t s = uw % kShards;
+        const uint32_t stride = (gridDim.x * (blockDim.x >> 6)) / kShards * 64u;
         const uint32_t n_s = counters[ctr_index(CTR_COUNT, depth, s)];
-        if (base < n_s) body(s * shard_cap + base + lane, base + lane < n_s, s);
+        for (uint32_t base = (uw / kShards) * 64u; base < n_s; base += stride)
+            body(s * shard_cap + base + lane, base + lane < n_s, s);
         return;
     }
     for (uint32_t k = 0; k < kShards; ++k) {
@@ -258,7 +265,13 @@ __device__ __forceinline__ void shade_batch(const PtShadeArgs& S, const PtDevSha
 {
     const uint32_t lane = threadIdx.x & 63;
     const float PI_F = 3.14159265f;
-    bool alive = false;
+    // Which paths go on is known from the hit alone, so the batch claims its slots in the next queue
+    // first and the atomic's round trip overlaps the gathers below.
+    const bool alive = valid && h.instance != 0xFFFFFFFFu && S.depth + 1 < S.max_depth;
+    const unsigned long long bal = __ballot(alive);
+    const uint32_t cnt = __popcll(bal);
+    uint32_t slot0 = 0;
+    if (cnt && lane == 0) slot0 = atomicAdd(&S.counters[ctr_index(CTR_COUNT, S.depth + 1, shard)], cnt);
     float4 no, nd, nw, nh;
     if (valid) {
         uint32_t seed_in, path;
@@ -277,22 +290,12 @@ __device__ __forceinline__ void shade_batch(const PtShadeArgs& S, const PtDevSha
             // closest_hit.rchit:57-60 (table chain pre-resolved per instance)
             const PtDevShadeInstance& I = shade_inst[h.instance];
             const float4 ptrs = I.ptrs;
-            const PtVertex* vertices = (const PtVertex*)ptr_from(ptrs.x, ptrs.y);
-            const uint32_t* indices = (const uint32_t*)ptr_from(ptrs.z, ptrs.w);
-            const uint32_t ia = indices[3 * (size_t)h.primitive + 0], ib = indices[3 * (size_t)h.primitive + 1], ic = indices[3 * (size_t)h.primitive + 2];
-            PtVertex A, B, C;
-            if ((((uintptr_t)vertices) & 15u) == 0) {
-                // 32-byte vertices on a 16-byte boundary: two 16-byte loads each instead of eight dwords
-                const float4* v4 = (const float4*)vertices;
-                const float4 a0 = v4[2 * (size_t)ia], a1 = v4[2 * (size_t)ia + 1];
-                const float4 b0_ = v4[2 * (size_t)ib], b1_ = v4[2 * (size_t)ib + 1];
-                const float4 c0 = v4[2 * (size_t)ic], c1 = v4[2 * (size_t)ic + 1];
-                A = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
-                B = { b0_.x, b0_.y, b0_.z, b0_.w, b1_.x, b1_.y, b1_.z, b1_.w };
-                C = { c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w };
-            } else {
-                A = vertices[ia]; B = vertices[ib]; C = vertices[ic];
-            }
+            // UnpackGeometry, closest_hit.rchit:33-53: the primitive's three vertices, gathered when the tables were bound
+            const float4* rec = (const float4*)ptr_from(ptrs.x, ptrs.y) + 6 * (size_t)h.primitive;
+            const float4 a0 = rec[0], a1 = rec[1], b0_ = rec[2], b1_ = rec[3], c0 = rec[4], c1 = rec[5];
+            const PtVertex A = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
+            const PtVertex B = { b0_.x, b0_.y, b0_.z, b0_.w, b1_.x, b1_.y, b1_.z, b1_.w };
+            const PtVertex C = { c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w };
             const float b0 = 1.0f - h.u - h.v, b1 = h.u, b2 = h.v;
 #define PT_MIX3(x, y, z) PT_FMA((z), b2, PT_FMA((y), b1, (x) * b0))
             float px = PT_MIX3(A.px, B.px, C.px), py = PT_MIX3(A.py, B.py, C.py), pz = PT_MIX3(A.pz, B.pz, C.pz);
@@ -350,8 +353,7 @@ __device__ __forceinline__ void shade_batch(const PtShadeArgs& S, const PtDevSha
             hv.x = PT_FMA(em.x, cw.x, hv.x);
             hv.y = PT_FMA(em.y, cw.y, hv.y);
             hv.z = PT_FMA(em.z, cw.z, hv.z);
-            if (S.depth + 1 < S.max_depth) {
-                alive = true;
+            if (alive) {
                 no = make_float4(wx, wy, wz, 0.0f);
                 nd = make_float4(Dx, Dy, Dz, 0.0f);
                 nw = make_float4(cw.x * wr, cw.y * wg, cw.z * wb, __uint_as_float(seed));
@@ -361,12 +363,8 @@ __device__ __forceinline__ void shade_batch(const PtShadeArgs& S, const PtDevSha
             }
         }
     }
-    // wave-level compaction into the same shard of the next queue: one atomic per batch
-    const unsigned long long bal = __ballot(alive);
-    const uint32_t cnt = __popcll(bal);
+    // wave-level compaction into the same shard of the next queue: one atomic per batch (issued above)
     if (cnt) {
-        uint32_t slot0 = 0;
-        if (lane == 0) slot0 = atomicAdd(&S.counters[ctr_index(CTR_COUNT, S.depth + 1, shard)], cnt);
         slot0 = __builtin_amdgcn_readfirstlane(slot0);
         if (alive) {
             const uint32_t slot = shard * S.shard_cap + slot0 + __popcll(bal & ((1ull << lane) - 1ull));
@@ -375,12 +373,14 @@ __device__ __forceinline__ void shade_batch(const PtShadeArgs& S, const PtDevSha
     }
 }
 
-// Launched with one wave per batch of the fullest shard rather than as a persistent grid: a shard
-// never holds more than at bounce 0, so the bounce-0 grid covers every level and waves past a
-// shard's end leave at once.  (Claiming batches one atomic at a time cost a persistent shade pass
-// two thirds of its time.)
+// A resident grid whose waves take batches by index: claiming batches one atomic at a time cost a
+// persistent shade pass two thirds of its time, and one wave per batch of a bounce-0-sized grid
+// cost 0.12 ms per level in waves launched only to find their shard shorter than that.
 #ifndef PT_SHADE_WAVES
 #define PT_SHADE_WAVES 4
+#endif
+#ifndef PT_SHADE_GRID
+#define PT_SHADE_GRID 1          // resident grids per launch
 #endif
 __global__ void __launch_bounds__(kBlock, PT_SHADE_WAVES)
 k_shade(PtShadeArgs A, const PtHit* __restrict__ hits)
@@ -541,17 +541,32 @@ int ensure_workspace(PtContext* ctx, PtLane& l, uint64_t paths, uint64_t pixels)
     return PT_OK;
 }
 
+// UnpackGeometry's gathers (closest_hit.rchit:33-53), done once per primitive instead of once per hit:
+// record p = the three 32-byte vertices indices[3p..3p+2] select, so shading reads 96 contiguous
+// bytes with no index load in front of them.
+__global__ void k_tri_records(const uint8_t* __restrict__ vertices, const uint32_t* __restrict__ indices, uint32_t n_prims,
+                              float* __restrict__ out)
+{
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // (primitive, corner, word)
+    if (g >= (size_t)n_prims * 24u) return;
+    const size_t corner = g >> 3; const uint32_t word = (uint32_t)g & 7u;
+    const float* v = (const float*)(vertices + sizeof(PtVertex) * (size_t)indices[corner]);
+    out[g] = v[word];
+}
+
 // Resolves blasInstances[custom] -> geometryNodes -> materials -> textures once per instance.
 int ensure_shade_records(PtContext* ctx, const PtTlas* tlas_c)
 {
     PtTlas* t = const_cast<PtTlas*>(tlas_c);
     if (t->shade_version == ctx->tables_version && ctx->tables_version != 0) return PT_OK;
     std::vector<PtDevShadeInstance> rec(t->n);
+    std::vector<PtTlas::TriRecords> fresh;
+    auto free_fresh = [&]() { (void)hipStreamSynchronize(ctx->stream); for (auto& f : fresh) (void)hipFree(f.dev); };
     auto split = [](uint64_t p, float& lo, float& hi) { uint32_t a = (uint32_t)p, b = (uint32_t)(p >> 32); memcpy(&lo, &a, 4); memcpy(&hi, &b, 4); };
     auto bits = [](uint32_t v) { float f; memcpy(&f, &v, 4); return f; };
     for (uint32_t i = 0; i < t->n; ++i) {
         const uint32_t custom = t->host_custom[i];
-        if (custom >= ctx->h_blas_instances.size()) { pt_set_error("pt_trace: instance %u has custom index %u but only %zu BLASInstance records exist", i, custom, ctx->h_blas_instances.size()); return PT_ERROR_INVALID_ARGUMENT; }
+        if (custom >= ctx->h_blas_instances.size()) { pt_set_error("pt_trace: instance %u has custom index %u but only %zu BLASInstance records exist", i, custom, ctx->h_blas_instances.size()); free_fresh(); return PT_ERROR_INVALID_ARGUMENT; }
         const PtGeometryNode& gn = ctx->h_geometry_nodes[ctx->h_blas_instances[custom].firstGeometryIndex];
         const PtMaterial& m = ctx->h_materials[gn.materialIndex];
         PtDevShadeInstance& r = rec[i];
@@ -560,8 +575,20 @@ int ensure_shade_records(PtContext* ctx, const PtTlas* tlas_c)
             r.o2w[k] = make_float4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
             r.w2o[k] = make_float4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
         }
-        split(gn.vertexBufferDeviceAddress, r.ptrs.x, r.ptrs.y);
-        split(gn.indexBufferDeviceAddress, r.ptrs.z, r.ptrs.w);
+        // the instance's triangle records: shared with every instance that names the same buffers
+        const uint32_t prims = t->host_prim_count[i];
+        size_t k = 0;
+        while (k < fresh.size() && !(fresh[k].vertices == gn.vertexBufferDeviceAddress && fresh[k].indices == gn.indexBufferDeviceAddress && fresh[k].prims == prims)) ++k;
+        if (k == fresh.size()) {
+            PtTlas::TriRecords tr; tr.vertices = gn.vertexBufferDeviceAddress; tr.indices = gn.indexBufferDeviceAddress; tr.prims = prims; tr.dev = nullptr;
+            if (!tr.vertices || !tr.indices) { pt_set_error("pt_trace: geometry node of instance %u has a null buffer address", i); free_fresh(); return PT_ERROR_INVALID_ARGUMENT; }
+            hipError_t e = hipMalloc((void**)&tr.dev, sizeof(float) * 24 * (size_t)prims);
+            if (e != hipSuccess) { pt_set_error("pt_trace: %s", hipGetErrorString(e)); free_fresh(); return PT_ERROR_HIP; }
+            fresh.push_back(tr);
+            k_tri_records<<<(uint32_t)(((size_t)prims * 24u + kBlock - 1) / kBlock), kBlock, 0, ctx->stream>>>((const uint8_t*)(uintptr_t)tr.vertices, (const uint32_t*)(uintptr_t)tr.indices, prims, (float*)tr.dev);
+        }
+        split((uint64_t)(uintptr_t)fresh[k].dev, r.ptrs.x, r.ptrs.y);
+        r.ptrs.z = r.ptrs.w = 0.0f;
         r.albedo = make_float4(m.albedoFactor[0], m.albedoFactor[1], m.albedoFactor[2], bits(m.useAlbedoMap ? 1u : 0u));
         r.emissive = make_float4(m.emissiveFactor[0], m.emissiveFactor[1], m.emissiveFactor[2], 0.0f);
         r.tex = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -572,7 +599,10 @@ int ensure_shade_records(PtContext* ctx, const PtTlas* tlas_c)
         }
     }
     int rc = pt_lanes_sync(ctx);
-    if (rc) return rc;
+    if (rc) { free_fresh(); return rc; }
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess) { free_fresh(); pt_set_error("pt_trace: building the triangle records failed"); return PT_ERROR_HIP; }
+    for (auto& old_rec : t->tri_records) (void)hipFree(old_rec.dev);
+    t->tri_records.swap(fresh);
     PT_HIP_CHECK(hipMemcpy(t->shade_inst, rec.data(), sizeof(PtDevShadeInstance) * t->n, hipMemcpyHostToDevice));
     t->shade_version = ctx->tables_version;
     return PT_OK;
@@ -646,6 +676,8 @@ int pt_trace(PtContext* ctx, const PtTlas* tlas, const float camera[32], uint32_
     primary.spp = spp; primary.W = width; primary.H = height; primary.frame = frame; primary.seed_mode = seed_mode;
     const int blocks_i = persistent_blocks(ctx, (const void*)k_intersect<false>);
     const int blocks_p = persistent_blocks(ctx, (const void*)k_primary);
+    // whole multiples of kShards waves
+    const int blocks_s = std::max(16, persistent_blocks(ctx, (const void*)k_shade) * PT_SHADE_GRID / 16 * 16);
     // Every chunk of the frame goes to the next lane and is left in flight there; only the
     // read-modify-write of the image is chained, in submission order.
     for (uint64_t p0 = 0; p0 < n_pixels; p0 += chunk_pixels) {
@@ -656,8 +688,6 @@ int pt_trace(PtContext* ctx, const PtTlas* tlas, const float camera[32], uint32_
         PtLane& w = *lane;
         if ((rc = ensure_workspace(ctx, w, (uint64_t)n_paths, n_pixels))) return rc;
         hipStream_t st = w.stream;
-        // one wave per batch of the fullest shard at bounce 0
-        const uint32_t blocks_flat = (uint32_t)((((uint64_t)n_paths + 63) / 64 + kShards - 1) / kShards * kShards + kBlock / 64 - 1) / (kBlock / 64);
         PT_HIP_CHECK(hipMemsetAsync(w.counters, 0, sizeof(uint32_t) * kCounterWords, st));
         primary.n_paths = n_paths; primary.pixel0 = (uint32_t)p0;
         k_init_counts<<<1, 64, 0, st>>>(n_paths, w.counters);
@@ -687,7 +717,7 @@ int pt_trace(PtContext* ctx, const PtTlas* tlas, const float camera[32], uint32_
                 k_intersect<false><<<blocks_i, kBlock, 0, st>>>(tv, w.counters, d, w.shard_cap, w.q[a][0], w.q[a][1],
                                                                 0.001f, 10000.0f, w.hits, nullptr, w.spill, sched_threshold(ctx, d));
                 if (ev_stop) PT_HIP_CHECK(hipEventRecord(ev_stop, st));
-                k_shade<<<blocks_flat, kBlock, 0, st>>>(sa, w.hits);
+                k_shade<<<blocks_s, kBlock, 0, st>>>(sa, w.hits);
             }
         }
         if (ctx->last_accumulate && ctx->last_accumulate != lane)

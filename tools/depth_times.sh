@@ -14,7 +14,7 @@ frames, cur = [], None
 for r in rows:
     n = r['Kernel_Name']; d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
     if 'k_init_counts' in n: cur = {'I': [], 'S': [], 't0': int(r['Start_Timestamp'])}; frames.append(cur)
-    elif cur is not None and 'k_intersect' in n: cur['I'].append(d)
+    elif cur is not None and ('k_intersect' in n or 'k_primary' in n): cur['I'].append(d)
     elif cur is not None and 'k_shade' in n: cur['S'].append(d)
     if cur is not None: cur['t1'] = int(r['End_Timestamp'])
 fr = frames[-4:]
