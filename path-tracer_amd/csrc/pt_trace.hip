@@ -259,9 +259,9 @@ struct PtShadeArgs {
 // FIRST: bounce 0, where the path weight is 1 and the collected radiance 0 and neither is read.
 template <bool FIRST>
 __device__ __forceinline__ void shade_batch(const PtShadeArgs& S, const PtDevShadeInstance* __restrict__ shade_inst,
-                                            const float4* __restrict__ q2, const float4* __restrict__ q3,
                                             float4* __restrict__ o0, float4* __restrict__ o1, float4* __restrict__ o2, float4* __restrict__ o3,
-                                            float4* __restrict__ path_result, uint32_t i, bool valid, uint32_t shard, const PtHit h)
+                                            float4* __restrict__ path_result, uint32_t i, bool valid, uint32_t shard, const PtHit h,
+                                            const float4 cw, float4 hv)
 {
     const uint32_t lane = threadIdx.x & 63;
     const float PI_F = 3.14159265f;
@@ -276,10 +276,8 @@ __device__ __forceinline__ void shade_batch(const PtShadeArgs& S, const PtDevSha
     if (valid) {
         uint32_t seed_in, path;
         if (FIRST) pt_primary_seed(S.primary, path_of_slot(i, shard, S.shard_cap), seed_in, path);
-        // the incoming ray is not needed here: the seed and the result slot travel in the spare
-        // words of the weight and radiance streams, so shading reads three streams, not five
-        const float4 cw = FIRST ? make_float4(1.0f, 1.0f, 1.0f, 0.0f) : q2[i];
-        float4 hv = FIRST ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : q3[i];
+        // cw, hv: path weight and collected radiance; bounces after the first carry the seed and the
+        // result slot in their spare words (the incoming ray is not needed here)
         if (!FIRST) { seed_in = __float_as_uint(cw.w); path = __float_as_uint(hv.w); }
         if (h.instance == 0xFFFFFFFFu) {
             // miss.rmiss:10-20
@@ -385,11 +383,28 @@ __device__ __forceinline__ void shade_batch(const PtShadeArgs& S, const PtDevSha
 __global__ void __launch_bounds__(kBlock, PT_SHADE_WAVES)
 k_shade(PtShadeArgs A, const PtHit* __restrict__ hits)
 {
-    for_each_batch<true>(A.counters, CTR_COUNT, A.depth, A.shard_cap, [&](uint32_t i, bool valid, uint32_t shard) {
-        PtHit h; h.instance = 0xFFFFFFFFu; h.primitive = 0u; h.u = h.v = 0.0f;
-        if (valid) h = hits[i];
-        shade_batch<false>(A, A.shade_inst, A.q2, A.q3, A.o0, A.o1, A.o2, A.o3, A.path_result, i, valid, shard, h);
-    });
+    // wave g of the grid serves shard g % kShards and every (grid waves / kShards)-th batch of it; the
+    // next batch's streams are requested before the current batch is shaded
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t uw = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const uint32_t s = uw % kShards;
+    const uint32_t stride = (gridDim.x * (blockDim.x >> 6)) / kShards * 64u;
+    const uint32_t n_s = A.counters[ctr_index(CTR_COUNT, A.depth, s)];
+    const float4* __restrict__ q2 = A.q2; const float4* __restrict__ q3 = A.q3;
+    uint32_t base = (uw / kShards) * 64u;
+    if (base >= n_s) return;
+    PtHit h; h.instance = 0xFFFFFFFFu; h.primitive = 0u; h.u = h.v = 0.0f;
+    float4 cw = make_float4(0.0f, 0.0f, 0.0f, 0.0f), hv = cw;
+    if (base + lane < n_s) { const uint32_t i = s * A.shard_cap + base + lane; h = hits[i]; cw = q2[i]; hv = q3[i]; }
+    for (;;) {
+        const uint32_t next = base + stride;
+        PtHit h1; h1.instance = 0xFFFFFFFFu; h1.primitive = 0u; h1.u = h1.v = 0.0f;
+        float4 cw1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), hv1 = cw1;
+        if (next + lane < n_s) { const uint32_t i1 = s * A.shard_cap + next + lane; h1 = hits[i1]; cw1 = q2[i1]; hv1 = q3[i1]; }
+        shade_batch<false>(A, A.shade_inst, A.o0, A.o1, A.o2, A.o3, A.path_result, s * A.shard_cap + base + lane, base + lane < n_s, s, h, cw, hv);
+        if (next >= n_s) break;
+        base = next; h = h1; cw = cw1; hv = hv1;
+    }
 }
 
 // Bounce 0 in one kernel: the primary ray is computed from the path index, traced with the plain
@@ -411,7 +426,8 @@ k_primary(PtTlasView tl, PtShadeArgs A, float tmin, float tmax, int* __restrict_
             pt_closest_hit(tl, stk, ox, oy, oz, dx, dy, dz, tmin, tmax, r);
             h.instance = r.inst; h.primitive = r.prim; h.u = r.u; h.v = r.v;
         }
-        shade_batch<true>(A, A.shade_inst, A.q2, A.q3, A.o0, A.o1, A.o2, A.o3, A.path_result, i, valid, shard, h);
+        shade_batch<true>(A, A.shade_inst, A.o0, A.o1, A.o2, A.o3, A.path_result, i, valid, shard, h,
+                          make_float4(1.0f, 1.0f, 1.0f, 0.0f), make_float4(0.0f, 0.0f, 0.0f, 0.0f));
     });
 }
 
