@@ -10,6 +10,20 @@
 #define PT_FMA(a, b, c) __builtin_fmaf((a), (b), (c))
 #define PT_DIR_EPS 8.271806125530277e-25f   // 2^-80
 
+// Queue reads and writes: 16 bytes, 16-byte aligned, touched once, marked non-temporal so that they
+// do not displace the BVH in L2 (worth 0.7 % on the dragon frame).
+typedef float pt_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 pt_stream_load(const float4* p)
+{
+    const pt_v4f v = __builtin_nontemporal_load((const pt_v4f*)p);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void pt_stream_store(float4* p, const float4 v)
+{
+    pt_v4f w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
+    __builtin_nontemporal_store(w, (pt_v4f*)p);
+}
+
 struct PtRaySpace {
     float ox, oy, oz, dx, dy, dz;
     float ix, iy, iz;        // 1 / d with |d| clamped away from zero

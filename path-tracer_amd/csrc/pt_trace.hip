@@ -366,7 +366,7 @@ __device__ __forceinline__ void shade_batch(const PtShadeArgs& S, const PtDevSha
         slot0 = __builtin_amdgcn_readfirstlane(slot0);
         if (alive) {
             const uint32_t slot = shard * S.shard_cap + slot0 + __popcll(bal & ((1ull << lane) - 1ull));
-            o0[slot] = no; o1[slot] = nd; o2[slot] = nw; o3[slot] = nh;
+            pt_stream_store(&o0[slot], no); pt_stream_store(&o1[slot], nd); pt_stream_store(&o2[slot], nw); pt_stream_store(&o3[slot], nh);
         }
     }
 }
@@ -395,12 +395,12 @@ k_shade(PtShadeArgs A, const PtHit* __restrict__ hits)
     if (base >= n_s) return;
     PtHit h; h.instance = 0xFFFFFFFFu; h.primitive = 0u; h.u = h.v = 0.0f;
     float4 cw = make_float4(0.0f, 0.0f, 0.0f, 0.0f), hv = cw;
-    if (base + lane < n_s) { const uint32_t i = s * A.shard_cap + base + lane; h = hits[i]; cw = q2[i]; hv = q3[i]; }
+    if (base + lane < n_s) { const uint32_t i = s * A.shard_cap + base + lane; { const float4 hh = pt_stream_load((const float4*)&hits[i]); h.instance = __float_as_uint(hh.x); h.primitive = __float_as_uint(hh.y); h.u = hh.z; h.v = hh.w; } cw = pt_stream_load(&q2[i]); hv = pt_stream_load(&q3[i]); }
     for (;;) {
         const uint32_t next = base + stride;
         PtHit h1; h1.instance = 0xFFFFFFFFu; h1.primitive = 0u; h1.u = h1.v = 0.0f;
         float4 cw1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), hv1 = cw1;
-        if (next + lane < n_s) { const uint32_t i1 = s * A.shard_cap + next + lane; h1 = hits[i1]; cw1 = q2[i1]; hv1 = q3[i1]; }
+        if (next + lane < n_s) { const uint32_t i1 = s * A.shard_cap + next + lane; { const float4 hh = pt_stream_load((const float4*)&hits[i1]); h1.instance = __float_as_uint(hh.x); h1.primitive = __float_as_uint(hh.y); h1.u = hh.z; h1.v = hh.w; } cw1 = pt_stream_load(&q2[i1]); hv1 = pt_stream_load(&q3[i1]); }
         shade_batch<false>(A, A.shade_inst, A.o0, A.o1, A.o2, A.o3, A.path_result, s * A.shard_cap + base + lane, base + lane < n_s, s, h, cw, hv);
         if (next >= n_s) break;
         base = next; h = h1; cw = cw1; hv = hv1;

@@ -109,7 +109,8 @@ __device__ __forceinline__ void pt_traverse_sched(const PtTlasView& tl, const Pt
             if (v == PT_NODE_DONE) {
                 PtHit out; out.instance = best.inst; out.primitive = best.prim; out.u = best.u; out.v = best.v;
                 const uint32_t dst = BY_ID ? __float_as_uint(q1[qi].w) : qi;
-                hits[dst] = out;
+                if (BY_ID) hits[dst] = out;     // the caller's array: no alignment beyond the record's own
+                else pt_stream_store((float4*)&hits[dst], make_float4(__uint_as_float(out.instance), __uint_as_float(out.primitive), out.u, out.v));
                 if (BY_ID && t_out) t_out[dst] = best.t;
             }
             node = v;
@@ -149,7 +150,7 @@ __device__ __forceinline__ void pt_traverse_sched(const PtTlasView& tl, const Pt
                 const uint32_t rank = __popcll(idle & lt_mask);
                 if (node == PT_NODE_DONE && rank < take) {
                     qi = wcur + rank;
-                    const float4 o = q0[qi], d = q1[qi];
+                    const float4 o = pt_stream_load(&q0[qi]), d = pt_stream_load(&q1[qi]);
                     pt_ray_space_init(cur, o.x, o.y, o.z, d.x, d.y, d.z);
                     ws[0 * PT_TRAVERSE_BLOCK] = cur.ox; ws[1 * PT_TRAVERSE_BLOCK] = cur.oy; ws[2 * PT_TRAVERSE_BLOCK] = cur.oz;
                     ws[3 * PT_TRAVERSE_BLOCK] = cur.dx; ws[4 * PT_TRAVERSE_BLOCK] = cur.dy; ws[5 * PT_TRAVERSE_BLOCK] = cur.dz;
