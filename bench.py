@@ -198,21 +198,34 @@ def main():
         texf = cpu["textured_hit_fraction"] if cpu else 0.29
         bytes_intersect = 32.0 * vn + 36.0 * vt + 48.0
         bytes_pipeline = 32.0 * vn + 36.0 * vt + hitf * 336.0 + texf * 16.0 + 176.0
-        i_ms, i_rays, i_n = float(prof["intersect_ms"]), float(prof["intersect_rays"]), int(prof["intersect_launches"])
+        # the traversal launches of a step: k_primary (bounce 0; its interval also holds the bounce's
+        # shading, which makes the figure conservative) and k_intersect (one per later bounce)
+        i_ms = float(prof["intersect_ms"]) + float(prof["primary_ms"])
+        i_rays = float(prof["intersect_rays"]) + float(prof["primary_rays"])
+        i_n = int(prof["intersect_launches"]) + int(prof["primary_launches"])
         achieved = (i_rays * bytes_intersect) / (i_ms * 1e-3) / 1e9 if i_ms > 0 else 0.0
         out["roofline"] = {
-            "bound": "hbm", "kernel": "k_intersect", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "bound": "hbm", "kernel": "k_intersect + k_primary", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": measured_traffic(f"{args.scene} {W}x{H} {args.spp}spp depth{args.max_depth} lanes{args.frames_in_flight}"),
             "launches": i_n, "avg_launch_ms": i_ms / max(i_n, 1), "rays_per_launch": i_rays / max(i_n, 1),
             "frames_in_flight": args.frames_in_flight,
             "bytes_per_ray": bytes_intersect, "box_tests_per_ray": vn, "tri_tests_per_ray": vt,
             "intersect_rays_per_s": i_rays / (i_ms * 1e-3) if i_ms > 0 else 0.0,
+            "per_kernel": {
+                "k_primary": {"launches": int(prof["primary_launches"]),
+                              "avg_launch_ms": float(prof["primary_ms"]) / max(int(prof["primary_launches"]), 1),
+                              "rays_per_launch": float(prof["primary_rays"]) / max(int(prof["primary_launches"]), 1)},
+                "k_intersect": {"launches": int(prof["intersect_launches"]),
+                                "avg_launch_ms": float(prof["intersect_ms"]) / max(int(prof["intersect_launches"]), 1),
+                                "rays_per_launch": float(prof["intersect_rays"]) / max(int(prof["intersect_launches"]), 1)}},
             "pipeline_bytes_per_ray": bytes_pipeline,
             "pipeline_frac": (rays / elapsed / world) * bytes_pipeline / 1e9 / HBM_PEAK_GBS,
         }
         if prof_serial is not None and float(prof_serial["intersect_ms"]) > 0:
-            s_ms, s_rays, s_n = float(prof_serial["intersect_ms"]), float(prof_serial["intersect_rays"]), int(prof_serial["intersect_launches"])
+            s_ms = float(prof_serial["intersect_ms"]) + float(prof_serial["primary_ms"])
+            s_rays = float(prof_serial["intersect_rays"]) + float(prof_serial["primary_rays"])
+            s_n = int(prof_serial["intersect_launches"]) + int(prof_serial["primary_launches"])
             s_ach = (s_rays * bytes_intersect) / (s_ms * 1e-3) / 1e9
             # launches of frames in flight share the GPU, which stretches each of them; this is the
             # same measurement with frames strictly one after the other

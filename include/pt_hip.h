@@ -204,9 +204,12 @@ int pt_trace_stats_reset(PtContext* ctx);
  * returns them.  With several frames in flight the launches of different frames overlap, so the
  * sum is kernel time, not elapsed time.  Has no counterpart in the reference (it has no timers). */
 typedef struct PtTraceProfile {
-    uint64_t intersect_launches;
+    uint64_t intersect_launches;   /* k_intersect: bounces after the first */
     uint64_t intersect_rays;
     double   intersect_ms;
+    uint64_t primary_launches;     /* k_primary: bounce 0, traced and shaded in one kernel */
+    uint64_t primary_rays;
+    double   primary_ms;
 } PtTraceProfile;
 int pt_ctx_set_profiling(PtContext* ctx, int enabled);
 int pt_trace_profile(PtContext* ctx, PtTraceProfile* out);

@@ -144,6 +144,7 @@ struct PtContext {
     bool profiling = false;
     std::vector<hipEvent_t> ev_pool;           // pairs: start, stop
     size_t ev_used = 0;
+    std::vector<uint8_t> ev_primary;           // per pair: the launch was bounce 0 (k_primary)
     std::vector<uint32_t> ev_depth;            // depth of each recorded pair
     uint64_t stats_mark[PT_MAX_DEPTH] = {};    // rays_per_depth at the last pt_trace_profile
 };

@@ -718,6 +718,8 @@ int pt_trace(PtContext* ctx, const PtTlas* tlas, const float camera[32], uint32_
                 }
                 PT_HIP_CHECK(hipEventRecord(ctx->ev_pool[ctx->ev_used], st));
                 ev_stop = ctx->ev_pool[ctx->ev_used + 1];
+                if (ctx->ev_primary.size() < ctx->ev_used / 2 + 1) ctx->ev_primary.resize(ctx->ev_used / 2 + 1);
+                ctx->ev_primary[ctx->ev_used / 2] = d == 0;
                 ctx->ev_used += 2;
             }
             PtShadeArgs sa;
@@ -788,14 +790,14 @@ int pt_trace_profile(PtContext* ctx, PtTraceProfile* out)
     for (size_t k = 0; k + 1 < ctx->ev_used; k += 2) {
         float ms = 0.0f;
         PT_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev_pool[k], ctx->ev_pool[k + 1]));
-        out->intersect_ms += ms;
-        out->intersect_launches++;
+        if (ctx->ev_primary[k / 2]) { out->primary_ms += ms; out->primary_launches++; }
+        else { out->intersect_ms += ms; out->intersect_launches++; }
     }
     ctx->ev_used = 0;
     if (ctx->ws.stats) {
         uint64_t h[PT_MAX_DEPTH + 1];
         PT_HIP_CHECK(hipMemcpy(h, ctx->ws.stats, sizeof h, hipMemcpyDeviceToHost));
-        for (int d = 0; d < PT_MAX_DEPTH; ++d) { out->intersect_rays += h[d] - ctx->stats_mark[d]; ctx->stats_mark[d] = h[d]; }
+        for (int d = 0; d < PT_MAX_DEPTH; ++d) { (d == 0 ? out->primary_rays : out->intersect_rays) += h[d] - ctx->stats_mark[d]; ctx->stats_mark[d] = h[d]; }
     }
     return PT_OK;
 }

@@ -22,7 +22,8 @@ ACCUM_SUM_F32, ACCUM_MEAN_F32, ACCUM_MEAN_UNORM8 = 0, 1, 2
 
 AS_INFO = np.dtype([("node_count", "<u4"), ("prim_count", "<u4"), ("root_lo", "<f4", 3), ("root_hi", "<f4", 3),
                     ("delta", "<f4"), ("build_ms", "<f4")])
-TRACE_PROFILE = np.dtype([("intersect_launches", "<u8"), ("intersect_rays", "<u8"), ("intersect_ms", "<f8")])
+TRACE_PROFILE = np.dtype([("intersect_launches", "<u8"), ("intersect_rays", "<u8"), ("intersect_ms", "<f8"),
+                          ("primary_launches", "<u8"), ("primary_rays", "<u8"), ("primary_ms", "<f8")])
 TRACE_STATS = np.dtype([("rays_per_depth", "<u8", PT_MAX_DEPTH), ("rays", "<u8"), ("paths", "<u8")])
 
 # every symbol include/pt_hip.h declares: (restype, argtypes)

@@ -39,7 +39,7 @@ def test_struct_layouts_match_header():
         "PtBvhNode": ["lo0", "hi0", "lo1", "hi1", "c0", "c1"],
         "PtAsInfo": ["node_count", "prim_count", "root_lo", "root_hi", "delta", "build_ms"],
         "PtTraceStats": ["rays_per_depth", "rays", "paths"],
-        "PtTraceProfile": ["intersect_launches", "intersect_rays", "intersect_ms"],
+        "PtTraceProfile": ["intersect_launches", "intersect_rays", "intersect_ms", "primary_launches", "primary_rays", "primary_ms"],
     }
     src = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void){"]
     for s, fs in fields.items():

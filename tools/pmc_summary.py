@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Summarises rocprofv3 --pmc CSVs written by tools/pmc_passes.sh: per kernel (and per launch of
 the intersect / shade kernels of the last traced frame) the counter values.
-usage: tools/pmc_summary.py <dir> [--per-launch]"""
+usage: tools/pmc_summary.py <dir> [--per-launch] [--all]"""
 import csv
 import glob
 import sys
@@ -16,8 +16,8 @@ for f in sorted(glob.glob(f"{d}/pass*/*/*counter_collection.csv")):
         short = "k_" + k.split("k_", 1)[1].split("(")[0].split("<")[0] if "k_" in k else k[:40]
         vals[short][r["Counter_Name"]].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
 for k in sorted(vals):
-    if not k.startswith("k_"):
-        continue
+    if k not in ("k_intersect", "k_primary", "k_shade", "k_accumulate") and "--all" not in sys.argv:
+        continue                      # the one-time builder kernels only with --all
     print(f"== {k}")
     for c in sorted(vals[k]):
         v = [x for _, x in sorted(vals[k][c])]

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""HBM-side traffic of the intersect kernel from the FETCH_SIZE / WRITE_SIZE passes of
+"""HBM-side traffic of the traversal kernels (k_primary, k_intersect) from the FETCH_SIZE / WRITE_SIZE passes of
 tools/pmc_passes.sh, per launch.  rocprofv3 reports both in KiB; on gfx950 FETCH_SIZE tallies the
 128-byte requests of 16-byte-per-lane reads at 64 bytes, so it is doubled; WRITE_SIZE is exact.
 usage: tools/pmc_traffic.py <pmc dir> <bench args recorded with the result...>  -> JSON on stdout"""
@@ -13,13 +13,13 @@ tot = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0}
 launches = {"FETCH_SIZE": 0, "WRITE_SIZE": 0}
 for f in sorted(glob.glob(f"{d}/pass*/*/*counter_collection.csv")):
     for r in csv.DictReader(open(f)):
-        if "k_intersect" in r["Kernel_Name"] and r["Counter_Name"] in tot:
+        if ("k_intersect" in r["Kernel_Name"] or "k_primary" in r["Kernel_Name"]) and r["Counter_Name"] in tot:
             tot[r["Counter_Name"]] += float(r["Counter_Value"])
             launches[r["Counter_Name"]] += 1
 n = launches["FETCH_SIZE"]
 assert n and n == launches["WRITE_SIZE"], launches
 fetch = tot["FETCH_SIZE"] * 1024.0 * 2.0
 write = tot["WRITE_SIZE"] * 1024.0
-print(json.dumps({"kernel": "k_intersect", "launches": n, "fetch_bytes_per_launch": fetch / n, "write_bytes_per_launch": write / n,
+print(json.dumps({"kernel": "k_intersect + k_primary", "launches": n, "fetch_bytes_per_launch": fetch / n, "write_bytes_per_launch": write / n,
                   "bytes_per_launch": (fetch + write) / n, "corrections": "FETCH_SIZE KiB x 1024 x 2 (gfx950), WRITE_SIZE KiB x 1024",
                   "command": "bench.py " + " ".join(sys.argv[2:])}))
