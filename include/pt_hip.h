@@ -170,7 +170,9 @@ int pt_tlas_wide_download(const PtTlas* tlas, void* nodes64, uint32_t capacity, 
 
 /* Replaces BindlessResources::UpdateDescriptorSet (source/resources/bindless_resources.cpp:70-76,
  * bindings 0-3 of set 0, :250-274): copies the four tables to the GPU.  Table sizes are capped at
- * 1024 entries like the reference (include/resources/bindless_resources.hpp:65). */
+ * 1024 entries like the reference (include/resources/bindless_resources.hpp:65).
+ * The vertices a geometry node addresses are read when a TLAS is next traced (per-primitive copies
+ * for shading); call again after changing vertex or index data in place. */
 int pt_scene_set_tables(PtContext* ctx,
                         const PtMaterial* materials, uint32_t n_materials,
                         const PtGeometryNode* geometry_nodes, uint32_t n_geometry_nodes,
