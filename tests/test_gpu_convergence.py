@@ -1,0 +1,64 @@
+"""Monte-Carlo convergence on the GPU: the root-mean-square error of an N-sample Cornell image against
+a 65,536-sample image of the same seeds' family falls like 1/sqrt(N).
+
+The estimator has no pixel jitter (shaders/ray_gen.rgen:21-27), so the images differ by sampling
+noise alone; sample i of frame f draws from TEA(pixel, f * spp + i), so frame 0 at N samples per
+pixel is the first N samples of the reference's 65,536 and the expected squared error is
+sigma^2 (1/N - 1/M)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+W = H = 128
+M_FRAMES, M_SPP = 64, 1024          # 65,536 samples per pixel
+
+
+def _image(r, spp, frames):
+    from pt_amd import hip
+    acc = r.ctx.alloc_zeros(W * H * 16)
+    try:
+        for f in range(frames):
+            r.render(spp=spp, max_depth=10, accum_mode=hip.ACCUM_SUM_F32, accum_dev=acc, frame=f)
+        a = r.ctx.download(acc, W * H * 16, np.float32).reshape(H, W, 4)
+    finally:
+        r.ctx.free(acc)
+    assert np.all(a[..., 3] == frames)
+    return a[..., :3].astype(np.float64) / frames
+
+
+def test_rmse_falls_like_one_over_sqrt_n(cornell):
+    from pt_amd import hip
+    r = hip.Renderer(cornell, W, H)
+    try:
+        ref = _image(r, M_SPP, M_FRAMES)
+        m = M_FRAMES * M_SPP
+        ns = [16, 64, 256, 1024, 4096]
+        rmse = []
+        for n in ns:
+            img = _image(r, n, 1)
+            rmse.append(float(np.sqrt(np.mean((img - ref) ** 2))))
+    finally:
+        r.close()
+    assert np.isfinite(ref).all() and ref.mean() > 0.05
+    # strictly falling, and by close to a factor of two for every fourfold N
+    for a, b in zip(rmse, rmse[1:]):
+        assert 1.6 < a / b < 2.5, rmse
+    # sigma estimated from each N agrees: rmse^2 = sigma^2 (1/N - 1/M)
+    sigma = [e / np.sqrt(1.0 / n - 1.0 / m) for e, n in zip(rmse, ns)]
+    assert max(sigma) / min(sigma) < 1.25, sigma
+    # at 4096 samples the image is within 3 % (rms) of the reference's mean level
+    assert rmse[-1] < 0.03 * ref.mean(), (rmse[-1], ref.mean())
+
+
+def test_frames_are_disjoint_sample_sets(cornell):
+    """64 frames of 16 samples and 16 frames of 64 samples are the same 1,024 samples per pixel:
+    the images agree up to the order of the float additions."""
+    from pt_amd import hip
+    r = hip.Renderer(cornell, W, H)
+    try:
+        a = _image(r, 16, 64)
+        b = _image(r, 64, 16)
+    finally:
+        r.close()
+    assert np.allclose(a, b, rtol=2e-5, atol=1e-6)
