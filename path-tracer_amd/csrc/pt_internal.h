@@ -115,8 +115,12 @@ struct PtWorkspace {                   // shared by all lanes
 };
 
 // Per-lane traversal stack capacity: entries in LDS, then entries in a per-thread global slice.
+#ifndef PT_LDS_STACK
 #define PT_LDS_STACK 24
+#endif
+#ifndef PT_SPILL_STACK
 #define PT_SPILL_STACK 104
+#endif
 
 struct PtContext {
     int device = 0;

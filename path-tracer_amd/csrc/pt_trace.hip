@@ -410,7 +410,10 @@ k_shade(PtShadeArgs A, const PtHit* __restrict__ hits)
 // Bounce 0 in one kernel: the primary ray is computed from the path index, traced with the plain
 // schedule (primary rays are coherent) and shaded where it ends, so no hit record is written and
 // read back, and the shading traffic overlaps the arithmetic of the other waves' traversal.
-__global__ void __launch_bounds__(kBlock, PT_INTERSECT_WAVES)
+#ifndef PT_PRIMARY_WAVES
+#define PT_PRIMARY_WAVES 4
+#endif
+__global__ void __launch_bounds__(kBlock, PT_PRIMARY_WAVES)
 k_primary(PtTlasView tl, PtShadeArgs A, float tmin, float tmax, int* __restrict__ spill)
 {
     __shared__ int s_stack[PT_LDS_STACK][kBlock];
