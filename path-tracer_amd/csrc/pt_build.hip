@@ -951,6 +951,10 @@ static void invert_transform(const float m[12], float w[12])
     w[8] = (float)i20; w[9] = (float)i21; w[10] = (float)i22; w[11] = (float)(-((i20 * t0 + i21 * t1) + i22 * t2));
 }
 
+#ifndef PT_TINY_BLAS
+#define PT_TINY_BLAS 4u
+#endif
+
 int pt_tlas_build(PtContext* ctx, const PtInstance* instances, uint32_t n, PtTlas** out)
 {
     PT_REQUIRE(ctx && instances && out, "null argument");
@@ -1046,7 +1050,18 @@ int pt_tlas_build(PtContext* ctx, const PtInstance* instances, uint32_t n, PtTla
             pt_set_error("pt_tlas_build: acceleration structure too deep for the traversal stack (%u + %u wide levels)", t->wide_depth, depth_blas);
             (void)hipFree(tlas_wide); pt_tlas_destroy(t); return PT_ERROR_LIMIT;
         }
-        for (uint32_t i = 0; i < n; ++i) { float rootf; memcpy(&rootf, &root_of[blas_of_inst[i]], 4); di[i].q[5].x = rootf; }
+        // What a ray that enters instance i continues with: the BLAS's root node, or, for a BLAS of
+        // at most PT_TINY_BLAS triangles, one leaf over all of them (the instance's own box test has
+        // just passed; a node step in front of so few triangles costs more than it rejects).
+        const char* tiny_env = getenv("PT_HIP_TINY_BLAS");
+        const uint32_t tiny = tiny_env ? (uint32_t)atoi(tiny_env) : PT_TINY_BLAS;
+        for (uint32_t i = 0; i < n; ++i) {
+            const uint32_t k = blas_of_inst[i];
+            int32_t entry = (int32_t)root_of[k];
+            if (uniq[k]->prim_count <= tiny && uniq[k]->prim_count <= 8u)
+                entry = (int32_t)~((tri_base[k] << 3) | (uniq[k]->prim_count - 1u));
+            float f; memcpy(&f, &entry, 4); di[i].q[5].x = f;
+        }
         e = hipMalloc((void**)&t->pool_nodes, sizeof(PtWide4) * (size_t)total_nodes);
         if (e == hipSuccess) e = hipMalloc((void**)&t->pool_tris, sizeof(float4) * 3 * (size_t)(nt ? nt : 1));
         if (e == hipSuccess) {
