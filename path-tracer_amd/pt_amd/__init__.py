@@ -1,2 +1,2 @@
-"""Host-side Python mirror of the path tracer's hot-path API (see DESIGN.md at the repo root)."""
+"""Host-side Python mirror of the path tracer's hot-path API: ctypes binding of include/pt_hip.h, scene and table model, glTF import."""
 from . import abi, camera, scene  # noqa: F401
