@@ -1,17 +1,18 @@
 // pt_trace.hip -- the wavefront path-tracing pipeline that replaces vkCmdTraceRaysKHR
 // (source/renderer.cpp:122) and the three shaders it runs:
-//   (generate) shaders/ray_gen.rgen:21-47   primary ray + per-sample seed + payload reset: no pass of its
-//              own; bounce 0 computes them from the path index where they are used
-//   intersect  shaders/ray_gen.rgen:54-65   traceRayEXT (software two-level BVH traversal)
-//   shade      shaders/closest_hit.rchit:55-86 and shaders/miss.rmiss:8-21, plus the
-//              bounce bookkeeping of ray_gen.rgen:67-68; survivors are compacted into the next queue
-//   accumulate shaders/ray_gen.rgen:71-87   per-pixel sum over samples, running mean / sum
+//   k_primary    bounce 0 in one kernel: shaders/ray_gen.rgen:21-47 (primary ray, per-sample seed, payload
+//                reset: pure functions of the path index, computed in registers), the traceRayEXT of
+//                ray_gen.rgen:54-65 and the hit / miss shading of that bounce
+//   k_intersect  shaders/ray_gen.rgen:54-65   traceRayEXT of every later bounce (software two-level BVH traversal)
+//   k_shade      shaders/closest_hit.rchit:55-86 and shaders/miss.rmiss:8-21, plus the bounce
+//                bookkeeping of ray_gen.rgen:67-68; survivors are compacted into the next queue
+//   k_accumulate shaders/ray_gen.rgen:71-87   per-pixel sum over samples, running mean / sum
 //
 // Path state lives in four float4 streams per queue slot (ping-pong between bounces):
-//   q0 = (origin.xyz, bits(seed))   q1 = (direction.xyz, bits(path id))
-//   q2 = (currentWeight.rgb, -)     q3 = (hitValue.rgb, -)
+//   q0 = (origin.xyz, -)                         q1 = (direction.xyz, -)            read by traversal
+//   q2 = (currentWeight.rgb, bits(seed))         q3 = (hitValue.rgb, bits(path id)) read by shading
 // so every lane moves 16 bytes per access and a wave moves 1 KiB per instruction.  The "path id" is the
-// slot of the path's final radiance, laid out [sample][pixel of the chunk].  The streams come into being
+// slot of the path's final radiance, laid out [pixel of the chunk][sample].  The streams come into being
 // with the survivors of bounce 0; bounce 0 itself reads none of them.
 //
 // Ray queues are split into kShards independent shards, each with its own size and work counter
@@ -19,9 +20,9 @@
 // which for 33 M rays (half a million 64-ray batches) costs more than the traversal itself;
 // 64 heads remove that limit.  Traversal runs on a fixed persistent grid: every wave starts at the
 // shard matching its index, claims slots with one atomic per few batches and moves on to the next
-// shard when one runs dry.  Shading is launched with one wave per batch of the fullest possible
-// shard.  Either way sizes stay on the device and a frame needs no host round trip.
-// Survivors of shard s go to shard s of the next queue, which therefore never overflows.
+// shard when one runs dry.  Shading runs on a resident grid whose waves take the batches of their
+// shard by index, without atomics.  Either way sizes stay on the device and a frame needs no host
+// round trip.  Survivors of shard s go to shard s of the next queue, which therefore never overflows.
 #include "pt_device.h"
 #include "pt_traverse_sched.h"
 #include <string.h>
