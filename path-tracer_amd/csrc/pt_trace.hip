@@ -411,6 +411,9 @@ k_shade(PtShadeArgs A, const PtHit* __restrict__ hits)
 // Bounce 0 in one kernel: the primary ray is computed from the path index, traced with the plain
 // schedule (primary rays are coherent) and shaded where it ends, so no hit record is written and
 // read back, and the shading traffic overlaps the arithmetic of the other waves' traversal.
+#ifndef PT_PRIMARY_STATIC
+#define PT_PRIMARY_STATIC true     // batches by index (the image interleaves over the waves, so they balance) instead of claimed with atomics
+#endif
 #ifndef PT_PRIMARY_WAVES
 #define PT_PRIMARY_WAVES 4
 #endif
@@ -421,7 +424,7 @@ k_primary(PtTlasView tl, PtShadeArgs A, float tmin, float tmax, int* __restrict_
     PtStack stk;
     stk.lds = (pt_lds_int*)&s_stack[0][threadIdx.x];
     stk.spill_base = spill;
-    for_each_batch<false>(A.counters, CTR_WORK_INTERSECT, 0, A.shard_cap, [&](uint32_t i, bool valid, uint32_t shard) {
+    for_each_batch<PT_PRIMARY_STATIC>(A.counters, CTR_WORK_INTERSECT, 0, A.shard_cap, [&](uint32_t i, bool valid, uint32_t shard) {
         PtHit h; h.instance = 0xFFFFFFFFu; h.primitive = 0u; h.u = h.v = 0.0f;
         if (valid) {
             float ox, oy, oz, dx, dy, dz;
