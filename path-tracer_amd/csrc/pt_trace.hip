@@ -255,6 +255,13 @@ struct PtShadeArgs {
     PtPrimaryArg primary;
 };
 
+// miss.rmiss:10-20 followed by ray_gen.rgen:67: the miss colour times the path weight joins the radiance
+__device__ __forceinline__ void shade_miss(uint32_t depth, const float4 cw, float4& hv)
+{
+    const float e = depth == 0 ? 1.0f * 0.8f : 0.01f;
+    hv.x = PT_FMA(e, cw.x, hv.x); hv.y = PT_FMA(e, cw.y, hv.y); hv.z = PT_FMA(e, cw.z, hv.z);
+}
+
 // Shades the 64 slots of one batch (slot i per lane, hit h) and compacts the surviving paths into the
 // same shard of the next queue.  Called by every lane of the wave, valid or not.
 // FIRST: bounce 0, where the path weight is 1 and the collected radiance 0 and neither is read.
@@ -281,9 +288,7 @@ __device__ __forceinline__ void shade_batch(const PtShadeArgs& S, const PtDevSha
         // result slot in their spare words (the incoming ray is not needed here)
         if (!FIRST) { seed_in = __float_as_uint(cw.w); path = __float_as_uint(hv.w); }
         if (h.instance == 0xFFFFFFFFu) {
-            // miss.rmiss:10-20
-            const float e = S.depth == 0 ? 1.0f * 0.8f : 0.01f;
-            hv.x = PT_FMA(e, cw.x, hv.x); hv.y = PT_FMA(e, cw.y, hv.y); hv.z = PT_FMA(e, cw.z, hv.z);
+            shade_miss(S.depth, cw, hv);
             path_result[path] = hv;
         } else {
             // closest_hit.rchit:57-60 (table chain pre-resolved per instance)
@@ -381,30 +386,95 @@ __device__ __forceinline__ void shade_batch(const PtShadeArgs& S, const PtDevSha
 #ifndef PT_SHADE_GRID
 #define PT_SHADE_GRID 1          // resident grids per launch
 #endif
+#ifndef PT_SHADE_DENSE
+#define PT_SHADE_DENSE 40u        // percent of hits in a group above which it is shaded without sorting
+#endif
+#ifndef PT_SHADE_GROUP
+#define PT_SHADE_GROUP 4         // batches a wave sorts into misses and hits at a time
+#endif
+// Bounces after the first are mostly misses (69 % at bounce 1 of the dragon frame), and a miss costs a
+// few instructions while a hit costs a chain of gathers: shaded slot by slot, the chain runs with a
+// third of its lanes.  A wave therefore takes PT_SHADE_GROUP consecutive batches of its shard,
+// finishes the misses at once and collects the hits in LDS, then shades the hits 64 at a time.
 __global__ void __launch_bounds__(kBlock, PT_SHADE_WAVES)
 k_shade(PtShadeArgs A, const PtHit* __restrict__ hits)
 {
-    // wave g of the grid serves shard g % kShards and every (grid waves / kShards)-th batch of it; the
-    // next batch's streams are requested before the current batch is shaded
+    constexpr uint32_t kSpan = PT_SHADE_GROUP * 64u;
+    __shared__ uint32_t s_list[kBlock / 64][5][kSpan];      // per wave: slot, instance, primitive, u, v of the collected hits
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t uw = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const uint32_t s = uw % kShards;
-    const uint32_t stride = (gridDim.x * (blockDim.x >> 6)) / kShards * 64u;
+    const uint32_t stride = (gridDim.x * (blockDim.x >> 6)) / kShards * kSpan;
     const uint32_t n_s = A.counters[ctr_index(CTR_COUNT, A.depth, s)];
     const float4* __restrict__ q2 = A.q2; const float4* __restrict__ q3 = A.q3;
-    uint32_t base = (uw / kShards) * 64u;
-    if (base >= n_s) return;
-    PtHit h; h.instance = 0xFFFFFFFFu; h.primitive = 0u; h.u = h.v = 0.0f;
-    float4 cw = make_float4(0.0f, 0.0f, 0.0f, 0.0f), hv = cw;
-    if (base + lane < n_s) { const uint32_t i = s * A.shard_cap + base + lane; { const float4 hh = pt_stream_load((const float4*)&hits[i]); h.instance = __float_as_uint(hh.x); h.primitive = __float_as_uint(hh.y); h.u = hh.z; h.v = hh.w; } cw = pt_stream_load(&q2[i]); hv = pt_stream_load(&q3[i]); }
-    for (;;) {
-        const uint32_t next = base + stride;
-        PtHit h1; h1.instance = 0xFFFFFFFFu; h1.primitive = 0u; h1.u = h1.v = 0.0f;
-        float4 cw1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), hv1 = cw1;
-        if (next + lane < n_s) { const uint32_t i1 = s * A.shard_cap + next + lane; { const float4 hh = pt_stream_load((const float4*)&hits[i1]); h1.instance = __float_as_uint(hh.x); h1.primitive = __float_as_uint(hh.y); h1.u = hh.z; h1.v = hh.w; } cw1 = pt_stream_load(&q2[i1]); hv1 = pt_stream_load(&q3[i1]); }
-        shade_batch<false>(A, A.shade_inst, A.o0, A.o1, A.o2, A.o3, A.path_result, s * A.shard_cap + base + lane, base + lane < n_s, s, h, cw, hv);
-        if (next >= n_s) break;
-        base = next; h = h1; cw = cw1; hv = hv1;
+    float4* __restrict__ path_result = A.path_result;
+    uint32_t (*list)[kSpan] = s_list[threadIdx.x >> 6];
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    for (uint32_t base = (uw / kShards) * kSpan; base < n_s; base += stride) {
+        float4 hh[PT_SHADE_GROUP];
+#pragma unroll
+        for (uint32_t b = 0; b < PT_SHADE_GROUP; ++b) {
+            const uint32_t at = base + b * 64u + lane;
+            hh[b] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (at < n_s) hh[b] = pt_stream_load((const float4*)&hits[s * A.shard_cap + at]);
+        }
+        // how dense are the hits?  Above PT_SHADE_DENSE percent the batches are shaded as they lie
+        // (their hit records are already here), sorting would only add a trip through LDS
+        uint32_t n_valid = 0, n_hits = 0;
+#pragma unroll
+        for (uint32_t b = 0; b < PT_SHADE_GROUP; ++b) {
+            const bool valid = base + b * 64u + lane < n_s;
+            n_valid += __popcll(__ballot(valid));
+            n_hits += __popcll(__ballot(valid && __float_as_uint(hh[b].x) != 0xFFFFFFFFu));
+        }
+        if (n_hits * 100u > n_valid * PT_SHADE_DENSE) {
+#pragma unroll
+            for (uint32_t b = 0; b < PT_SHADE_GROUP; ++b) {
+                const uint32_t at = base + b * 64u + lane, i = s * A.shard_cap + at;
+                if (base + b * 64u >= n_s) break;
+                float4 cw = make_float4(0.0f, 0.0f, 0.0f, 0.0f), hv = cw;
+                if (at < n_s) { cw = pt_stream_load(&q2[i]); hv = pt_stream_load(&q3[i]); }
+                PtHit h; h.instance = __float_as_uint(hh[b].x); h.primitive = __float_as_uint(hh[b].y); h.u = hh[b].z; h.v = hh[b].w;
+                shade_batch<false>(A, A.shade_inst, A.o0, A.o1, A.o2, A.o3, path_result, i, at < n_s, s, h, cw, hv);
+            }
+            continue;
+        }
+        uint32_t n_list = 0;
+#pragma unroll
+        for (uint32_t b = 0; b < PT_SHADE_GROUP; ++b) {
+            const uint32_t at = base + b * 64u + lane, i = s * A.shard_cap + at;
+            const bool valid = at < n_s;
+            const bool miss = __float_as_uint(hh[b].x) == 0xFFFFFFFFu;
+            if (valid && miss) {
+                const float4 cw = pt_stream_load(&q2[i]);
+                float4 hv = pt_stream_load(&q3[i]);
+                shade_miss(A.depth, cw, hv);
+                path_result[__float_as_uint(hv.w)] = hv;
+            }
+            const unsigned long long bal = __ballot(valid && !miss);
+            if (valid && !miss) {
+                const uint32_t at_list = n_list + __popcll(bal & lt_mask);
+                list[0][at_list] = i; list[1][at_list] = __float_as_uint(hh[b].x); list[2][at_list] = __float_as_uint(hh[b].y);
+                list[3][at_list] = __float_as_uint(hh[b].z); list[4][at_list] = __float_as_uint(hh[b].w);
+            }
+            n_list += __popcll(bal);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (uint32_t k = 0; k < n_list; k += 64u) {
+            const bool valid = k + lane < n_list;
+            uint32_t i = 0;
+            PtHit h; h.instance = 0xFFFFFFFFu; h.primitive = 0u; h.u = h.v = 0.0f;
+            float4 cw = make_float4(0.0f, 0.0f, 0.0f, 0.0f), hv = cw;
+            if (valid) {
+                i = list[0][k + lane]; h.instance = list[1][k + lane]; h.primitive = list[2][k + lane];
+                h.u = __uint_as_float(list[3][k + lane]); h.v = __uint_as_float(list[4][k + lane]);
+                cw = pt_stream_load(&q2[i]); hv = pt_stream_load(&q3[i]);
+            }
+            shade_batch<false>(A, A.shade_inst, A.o0, A.o1, A.o2, A.o3, path_result, i, valid, s, h, cw, hv);
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
