@@ -199,17 +199,28 @@ __device__ __forceinline__ void pt_traverse_sched(const PtTlasView& tl, const Pt
             do {
                 { const int act_ = __popcll(__ballot(want_leaf)); (void)act_; PT_STAT(1, 1); PT_STAT(4, act_); }
                 if (want_leaf) {
+                    // up to two triangles of the leaf per step: both are requested at once, so a
+                    // two-triangle leaf (a quad) costs one memory round trip, not two
                     const uint32_t code = ~(uint32_t)node;
                     const uint32_t pos = code >> 3;
+                    const bool two = (code & 7u) != 0u;
                     const float4 a = tl.tris[3 * (size_t)pos + 0], b = tl.tris[3 * (size_t)pos + 1], c = tl.tris[3 * (size_t)pos + 2];
+                    float4 a2 = a, b2 = b, c2 = c;
+                    if (two) { a2 = tl.tris[3 * (size_t)pos + 3]; b2 = tl.tris[3 * (size_t)pos + 4]; c2 = tl.tris[3 * (size_t)pos + 5]; }
                     float t, u, v;
                     if (pt_tri_test(cur, delta, a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, t, u, v)) {
                         const uint32_t prim = __float_as_uint(c.y);
                         if (t > tmin && t < tmax && t >= tlo && t <= thi)
                             pt_hit_update(best, t, cur_inst, prim, u, v);
                     }
-                    // one triangle per step: first + 1, count - 1
-                    if (code & 7u) node = (int)~(code + 7u);
+                    if (two && pt_tri_test(cur, delta, a2.x, a2.y, a2.z, a2.w, b2.x, b2.y, b2.z, b2.w, c2.x, t, u, v)) {
+                        const uint32_t prim = __float_as_uint(c2.y);
+                        if (t > tmin && t < tmax && t >= tlo && t <= thi)
+                            pt_hit_update(best, t, cur_inst, prim, u, v);
+                    }
+                    // first + done, count - done
+                    const uint32_t done = two ? 2u : 1u;
+                    if ((code & 7u) >= done) node = (int)~(code + 7u * done);
                     else advance(stk.pop());
                     want_leaf = node < 0 && cur_inst != PT_NO_INSTANCE;
                 }
