@@ -88,7 +88,10 @@ def test_intersect_hit_ids_bit_exact(name, n, schedule, request, monkeypatch):
 
 
 @pytest.mark.parametrize("schedule", ["plain", "sched"])
-@pytest.mark.parametrize("name,w,h,spp", [("cornell", 128, 128, 16), ("cube", 96, 64, 8), ("dragon", 160, 90, 4), ("soup", 64, 64, 4)])
+@pytest.mark.parametrize("name,w,h,spp", [("cornell", 128, 128, 16), ("cube", 96, 64, 8), ("dragon", 160, 90, 4), ("soup", 64, 64, 4),
+                                          # the reference's 25 samples per frame on an odd image (batches straddle pixels, the last
+                                          # batch is partial), one sample, and more samples than a batch holds
+                                          ("cornell", 37, 23, 25), ("dragon", 53, 31, 1), ("cornell", 19, 11, 77)])
 def test_render_frame_bit_exact(name, w, h, spp, schedule, request, monkeypatch):
     monkeypatch.setenv("PT_HIP_TRAVERSAL", schedule)
     from pt_amd import camera
