@@ -1,6 +1,8 @@
 """GPU parity: the HIP path (through the C ABI) against the CPU oracle on identical inputs.
 Integer results (BVH topology, hit ids) and, because sin/cos and every operation order are pinned,
 all float results as well are compared bit for bit."""
+import os
+
 import numpy as np
 import pytest
 
@@ -335,5 +337,38 @@ def test_errors_are_reported(cornell):
             r.render(spp=70000)
         with pytest.raises(hip.PtError):
             r.render(spp=4, max_depth=64)
+    finally:
+        r.close()
+
+
+def test_shading_follows_the_geometry_nodes_buffers():
+    """closest_hit.rchit:57-60 reads vertices through the geometry node's addresses, not through what the
+    BLAS was built from: pointing the nodes at a second vertex buffer (same positions, mirrored
+    normals) and binding the tables again must give the image of a scene modelled that way."""
+    import copy
+    from pt_amd import camera, hip
+    from pt_amd.scene import Scene
+    path = os.path.join(os.path.dirname(__file__), "golden", "scene_cornell.npz")
+    scene, mirrored = Scene.load_npz(path), Scene.load_npz(path)
+    for m in mirrored.models:
+        m.vertices["normal"] *= -1.0
+    w = h = 48
+    cam = camera.camera_uniform(w, h)
+    want_plain, _ = _oracle(scene).render_frame(cam, w, h, frame=0, spp=8, threads=4)
+    want_mirrored, _ = _oracle(mirrored).render_frame(cam, w, h, frame=0, spp=8, threads=4)
+    assert not _float_eq(want_plain, want_mirrored)
+    r = _renderer(scene, w, h)
+    try:
+        r.render(spp=8, frame=0)
+        assert _float_eq(r.last_result(), want_plain)
+        # second vertex buffer per model; the BLASes keep the first
+        new_bufs = [r.ctx.upload(m.vertices) for m in mirrored.models]
+        gn = copy.deepcopy(r.geometry_nodes)
+        for k, inst in enumerate(scene.instances()):
+            gn[k]["vertexBufferDeviceAddress"] = new_bufs[inst.model]
+        hip._check(r.ctx.lib.pt_scene_set_tables(r.ctx.h, hip._p(r.materials), len(r.materials), hip._p(gn), len(gn),
+                                                 hip._p(r.blas_instances), len(r.blas_instances), hip._p(r.textures), len(r.textures)))
+        r.render(spp=8, frame=0)
+        assert _float_eq(r.last_result(), want_mirrored)
     finally:
         r.close()
