@@ -584,17 +584,53 @@ __global__ void k_sah_scatter(uint32_t n, const uint32_t* __restrict__ ids, cons
 
 inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
-struct DevMem {   // frees everything it allocated when it goes out of scope
-    std::vector<void*> ptrs;
+// Scratch memory of the builders.  A build makes some fifty short-lived device allocations, and a
+// hipMalloc / hipFree pair costs more than most of the kernels in between, so they are carved from
+// an arena the context keeps between builds (builds are synchronous on the context's stream, one
+// at a time).  Nested builders release in stack order: a DevMem returns the arena to where it
+// found it.  alloc_own is a plain hipMalloc for buffers that outlive the build.
+struct DevMem {
+    PtArena& arena;
+    size_t mark_chunk, mark_used;
+    std::vector<void*> own;
+    explicit DevMem(PtContext* ctx) : arena(ctx->build_arena), mark_chunk(ctx->build_arena.cur), mark_used(ctx->build_arena.used) {}
     template <typename T> hipError_t alloc(T** p, size_t count)
+    {
+        const size_t bytes = ((count * sizeof(T) > 0 ? count * sizeof(T) : 16) + 255) & ~(size_t)255;
+        while (arena.cur < arena.chunks.size() && arena.used + bytes > arena.chunks[arena.cur].second) { ++arena.cur; arena.used = 0; }
+        if (arena.cur == arena.chunks.size()) {
+            const size_t cap = bytes > ((size_t)32 << 20) ? bytes : ((size_t)32 << 20);
+            void* q = nullptr;
+            hipError_t e = hipMalloc(&q, cap);
+            if (e != hipSuccess) return e;
+            arena.chunks.push_back({ (char*)q, cap });
+            arena.used = 0;
+        }
+        *p = (T*)(arena.chunks[arena.cur].first + arena.used);
+        arena.used += bytes;
+        return hipSuccess;
+    }
+    template <typename T> hipError_t alloc_own(T** p, size_t count)
     {
         void* q = nullptr;
         hipError_t e = hipMalloc(&q, count * sizeof(T) > 0 ? count * sizeof(T) : 16);
-        if (e == hipSuccess) { ptrs.push_back(q); *p = (T*)q; }
+        if (e == hipSuccess) { own.push_back(q); *p = (T*)q; }
         return e;
     }
-    void release(void* p) { for (auto& q : ptrs) if (q == p) q = nullptr; }
-    ~DevMem() { for (void* q : ptrs) if (q) (void)hipFree(q); }
+    void release(void* p) { for (auto& q : own) if (q == p) q = nullptr; }
+    ~DevMem()
+    {
+        for (void* q : own) if (q) (void)hipFree(q);
+        arena.cur = mark_chunk; arena.used = mark_used;
+        // back at the start with several chunks: one chunk of their total size serves the next build whole
+        if (mark_chunk == 0 && mark_used == 0 && arena.chunks.size() > 1) {
+            size_t total = 0;
+            for (auto& c : arena.chunks) { total += c.second; (void)hipFree(c.first); }
+            arena.chunks.clear();
+            void* q = nullptr;
+            if (hipMalloc(&q, total) == hipSuccess) arena.chunks.push_back({ (char*)q, total });
+        }
+    }
 };
 
 int scan_exclusive(hipStream_t st, DevMem& mem, const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* total_dev, uint32_t* sums = nullptr)
@@ -637,16 +673,16 @@ int pt_build_sah(PtContext* ctx, const float* boxes, uint32_t n, uint32_t max_le
                  PtBvhNode** nodes_out, uint32_t* node_count_out, uint32_t** order_out)
 {
     hipStream_t st = ctx->stream;
-    DevMem mem;
+    DevMem mem(ctx);
     const uint32_t kBatch = 32768;                      // ranges whose bins are resident at once (44 MB)
     uint32_t *ids_a = nullptr, *ids_b = nullptr, *tof_a = nullptr, *tof_b = nullptr, *flags = nullptr, *left = nullptr;
     uint32_t *inner = nullptr, *offsets = nullptr, *total = nullptr;
     PtSahTask *tasks_a = nullptr, *tasks_b = nullptr; SahBinsOrd* bins = nullptr; PtBvhNode* nodes = nullptr; uint32_t* sums = nullptr;
     hipError_t e = hipSuccess;
-    if ((e = mem.alloc(&ids_a, n)) || (e = mem.alloc(&ids_b, n)) || (e = mem.alloc(&tof_a, n)) || (e = mem.alloc(&tof_b, n)) ||
+    if ((e = mem.alloc_own(&ids_a, n)) || (e = mem.alloc_own(&ids_b, n)) || (e = mem.alloc(&tof_a, n)) || (e = mem.alloc(&tof_b, n)) ||
         (e = mem.alloc(&flags, n)) || (e = mem.alloc(&left, n)) || (e = mem.alloc(&inner, n)) || (e = mem.alloc(&offsets, n)) ||
         (e = mem.alloc(&total, 4)) || (e = mem.alloc(&tasks_a, n)) || (e = mem.alloc(&tasks_b, n)) ||
-        (e = mem.alloc(&bins, kBatch)) || (e = mem.alloc(&nodes, n)) || (e = mem.alloc(&sums, div_up(n, kBlock) + 1))) {
+        (e = mem.alloc(&bins, kBatch)) || (e = mem.alloc_own(&nodes, n)) || (e = mem.alloc(&sums, div_up(n, kBlock) + 1))) {
         pt_set_error("pt_build_sah: hipMalloc failed: %s", hipGetErrorString(e)); return PT_ERROR_OUT_OF_MEMORY;
     }
     const uint32_t nb = div_up(n, kBlock);
@@ -688,7 +724,7 @@ int pt_build_sah(PtContext* ctx, const float* boxes, uint32_t n, uint32_t max_le
 int pt_build_wide(PtContext* ctx, const PtBvhNode* nodes_dev, uint32_t node_count, void** wide_out, uint32_t* count_out, uint32_t* depth_out)
 {
     hipStream_t st = ctx->stream;
-    DevMem mem;
+    DevMem mem(ctx);
     uint32_t *front_a = nullptr, *front_b = nullptr, *counts = nullptr, *offsets = nullptr, *total = nullptr;
     PtWide4* wide = nullptr;
     // every wide node stands for a distinct binary node
@@ -721,7 +757,7 @@ int pt_build_lbvh(PtContext* ctx, const float* boxes, uint32_t n, uint32_t max_l
                   PtBvhNode** nodes_out, uint32_t* node_count_out, uint32_t** leaf_prims_out, uint64_t** sorted_keys_out)
 {
     hipStream_t st = ctx->stream;
-    DevMem mem;
+    DevMem mem(ctx);
     uint32_t* cb = nullptr; uint64_t* keys = nullptr; uint32_t* vals = nullptr;
     PT_HIP_CHECK(mem.alloc(&cb, 8));
     PT_HIP_CHECK(mem.alloc(&keys, n));
@@ -816,7 +852,7 @@ int pt_blas_build(PtContext* ctx, const void* vertices_dev, uint32_t vertex_stri
     hipEvent_t ev0, ev1;
     PT_HIP_CHECK(hipEventCreate(&ev0)); PT_HIP_CHECK(hipEventCreate(&ev1));
     PT_HIP_CHECK(hipEventRecord(ev0, st));
-    DevMem mem;
+    DevMem mem(ctx);
     uint32_t* scal = nullptr; float* boxes = nullptr;
     PT_HIP_CHECK(mem.alloc(&scal, 8));          // [0] maxabs bits, [1..6] root box (ordered)
     PT_HIP_CHECK(mem.alloc(&boxes, (size_t)prim_count * 6));

@@ -93,6 +93,12 @@ struct PtTlas {
 // One frame in flight: its own stream and path queues, so that the thin late bounces of one frame
 // overlap the wide early bounces of the next.  The reference cycles its per-frame command buffers
 // and fences the same way (source/renderer.cpp:62, MAX_FRAMES_IN_FLIGHT in include/vk_common.hpp:6).
+// Device scratch of the builders, kept between builds: chunks of device memory, filled in order.
+struct PtArena {
+    std::vector<std::pair<char*, size_t>> chunks;
+    size_t cur = 0, used = 0;      // chunk being filled and bytes used in it
+};
+
 struct PtLane {
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;         // recorded after the latest kernel enqueued on this lane
@@ -149,6 +155,7 @@ struct PtContext {
     std::vector<hipEvent_t> ev_pool;           // pairs: start, stop
     size_t ev_used = 0;
     std::vector<uint8_t> ev_primary;           // per pair: the launch was bounce 0 (k_primary)
+    PtArena build_arena;
     std::vector<uint32_t> ev_depth;            // depth of each recorded pair
     uint64_t stats_mark[PT_MAX_DEPTH] = {};    // rays_per_depth at the last pt_trace_profile
 };
