@@ -494,28 +494,68 @@ k_sah_bins(uint32_t n, const uint32_t* __restrict__ ids, const float* __restrict
     }
 }
 
-__global__ void k_sah_decide(uint32_t t_lo, uint32_t t_hi, PtSahTask* __restrict__ tasks,
-                             const SahBinsOrd* __restrict__ bins, uint32_t max_leaf, const float* __restrict__ boxes,
-                             const uint32_t* __restrict__ ids, uint32_t* __restrict__ inner)
+// One wave per range.  Lane 16 * axis + q holds bin q of that axis; prefix and suffix unions run along
+// the 16 lanes of an axis, every lane prices the split after its bin, and the cheapest split with the
+// lowest (axis, bin) wins -- the first minimum of the serial search in pt_sah.h, whose second half
+// (pt_sah_finish) lane 0 then runs on the winner.
+__global__ void __launch_bounds__(64)
+k_sah_decide(uint32_t t_lo, uint32_t t_hi, PtSahTask* __restrict__ tasks,
+             const SahBinsOrd* __restrict__ bins, uint32_t max_leaf, const float* __restrict__ boxes,
+             const uint32_t* __restrict__ ids, uint32_t* __restrict__ inner)
 {
-    const uint32_t t = t_lo + blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t t = t_lo + blockIdx.x;
     if (t >= t_hi) return;
-    PtSahTask task = tasks[t];
+    const uint32_t lane = threadIdx.x;
+    const int ax = (int)(lane >> 4), q = (int)(lane & 15u);
+    const bool bin_lane = lane < 48u;
     const SahBinsOrd& O = bins[t - t_lo];
-    PtSahBinsF B;
     const float inf = __builtin_inff();
-    for (int ax = 0; ax < 3; ++ax) for (int q = 0; q < PT_SAH_BINS; ++q) {
-        const uint32_t c = O.cnt[ax][q];
-        B.cnt[ax][q] = c;
-        for (int k = 0; k < 3; ++k) {
-            // an empty bin still holds the identities, which do not decode to +-inf
-            B.lo[ax][q][k] = c ? ord2f(O.lo[ax][q][k]) : inf;
-            B.hi[ax][q][k] = c ? ord2f(O.hi[ax][q][k]) : -inf;
-        }
-    }
+    const PtSahTask* T = &tasks[t];
     float c6[6];
-    for (int k = 0; k < 3; ++k) { c6[k] = task.lo[k]; c6[3 + k] = task.hi[k]; }
-    pt_sah_decide(task, B, c6, max_leaf);
+    for (int k = 0; k < 3; ++k) { c6[k] = T->lo[k]; c6[3 + k] = T->hi[k]; }
+    const uint32_t n = T->b - T->a;
+    // this lane's bin; an empty bin still holds the identities, which do not decode to +-inf
+    uint32_t cnt = 0;
+    float lo[3] = { inf, inf, inf }, hi[3] = { -inf, -inf, -inf };
+    if (bin_lane) {
+        cnt = O.cnt[ax][q];
+        if (cnt) for (int k = 0; k < 3; ++k) { lo[k] = ord2f(O.lo[ax][q][k]); hi[k] = ord2f(O.hi[ax][q][k]); }
+    }
+    // inclusive prefix (bins 0..q) and suffix (bins q..15) along the axis
+    uint32_t pn = cnt, sn = cnt;
+    float pl[3], ph[3], sl[3], sh[3];
+    for (int k = 0; k < 3; ++k) { pl[k] = lo[k]; ph[k] = hi[k]; sl[k] = lo[k]; sh[k] = hi[k]; }
+    for (int off = 1; off < 16; off <<= 1) {
+        const uint32_t un = __shfl_up(pn, off, 16), dn = __shfl_down(sn, off, 16);
+        float ul[3], uh[3], dl[3], dh[3];
+        for (int k = 0; k < 3; ++k) {
+            ul[k] = __shfl_up(pl[k], off, 16); uh[k] = __shfl_up(ph[k], off, 16);
+            dl[k] = __shfl_down(sl[k], off, 16); dh[k] = __shfl_down(sh[k], off, 16);
+        }
+        if (q >= off) { pn += un; for (int k = 0; k < 3; ++k) { pl[k] = fminf(pl[k], ul[k]); ph[k] = fmaxf(ph[k], uh[k]); } }
+        if (q + off < 16) { sn += dn; for (int k = 0; k < 3; ++k) { sl[k] = fminf(sl[k], dl[k]); sh[k] = fmaxf(sh[k], dh[k]); } }
+    }
+    // the split after bin q: left = bins 0..q, right = bins q+1..15 (the next lane's suffix)
+    const uint32_t rn = __shfl_down(sn, 1, 16);
+    float rl[3], rh[3];
+    for (int k = 0; k < 3; ++k) { rl[k] = __shfl_down(sl[k], 1, 16); rh[k] = __shfl_down(sh[k], 1, 16); }
+    float cost = inf;
+    if (bin_lane && n > 1 && q < PT_SAH_BINS - 1 && c6[3 + ax] > c6[ax] && pn != 0 && rn != 0) {
+        const float c = pt_sah_area(pl, ph) * (float)pn + pt_sah_area(rl, rh) * (float)rn;
+        if (c < inf) cost = c;
+    }
+    // cheapest split, lowest lane on ties
+    float bc = cost; uint32_t bl = lane;
+    for (int off = 32; off > 0; off >>= 1) {
+        const float oc = __shfl_xor(bc, off); const uint32_t ol = __shfl_xor(bl, off);
+        if (oc < bc || (oc == bc && ol < bl)) { bc = oc; bl = ol; }
+    }
+    float w[12];
+    for (int k = 0; k < 3; ++k) { w[k] = __shfl(pl[k], bl); w[3 + k] = __shfl(ph[k], bl); w[6 + k] = __shfl(rl[k], bl); w[9 + k] = __shfl(rh[k], bl); }
+    if (lane != 0) return;
+    PtSahTask task = *T;
+    const bool have = bc < inf;
+    pt_sah_finish(task, have ? (int)(bl >> 4) : -1, (int)(bl & 15u), bc, w, w + 3, w + 6, w + 9, c6, max_leaf);
     if (task.kind == 2) pt_sah_positional_boxes(task, boxes, ids);
     tasks[t] = task;
     inner[t] = task.kind != 0 ? 1u : 0u;
@@ -696,7 +736,7 @@ int pt_build_sah(PtContext* ctx, const float* boxes, uint32_t n, uint32_t max_le
             const uint32_t t_hi = t_lo + kBatch < m ? t_lo + kBatch : m, mb = t_hi - t_lo;
             k_sah_reset<<<div_up(mb * (uint32_t)(sizeof(SahBinsOrd) / 4), kBlock), kBlock, 0, st>>>(mb, bins);
             k_sah_bins<<<nb, kBlock, 0, st>>>(n, ids_a, boxes, tof_a, t_lo, t_hi, tasks_a, bins);
-            k_sah_decide<<<div_up(mb, 64), 64, 0, st>>>(t_lo, t_hi, tasks_a, bins, max_leaf, boxes, ids_a, inner);
+            k_sah_decide<<<mb, 64, 0, st>>>(t_lo, t_hi, tasks_a, bins, max_leaf, boxes, ids_a, inner);
         }
         int rc = scan_exclusive(st, mem, inner, offsets, m, total, sums);
         if (rc) return rc;

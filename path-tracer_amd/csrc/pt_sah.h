@@ -48,6 +48,23 @@ PT_HD static inline int pt_sah_bin_of(const float* box, int axis, float clo, flo
     return q < 0 ? 0 : (q >= PT_SAH_BINS ? PT_SAH_BINS - 1 : q);
 }
 
+// Second half of a range's decision, given the cheapest split (best_ax < 0: none exists; cost `best`,
+// children's boxes lo0..hi1): leaf, binned split or split by position.  Shared by the serial search
+// below and the GPU builder's wave-parallel search, so both decide alike.
+PT_HD static inline void pt_sah_finish(PtSahTask& t, int best_ax, int best_bin, float best, const float lo0[3], const float hi0[3],
+                                       const float lo1[3], const float hi1[3], const float cb[6], uint32_t max_leaf)
+{
+    const uint32_t n = t.b - t.a;
+    const bool have = best_ax >= 0;
+    const bool can_leaf = t.parent >= 0 && n <= max_leaf;
+    const float A = pt_sah_area(t.lo, t.hi);
+    if (n == 1 || (can_leaf && (!have || (float)n * A <= A + best))) { t.kind = 0; return; }
+    if (!have) { t.kind = 2; return; }            // child boxes of a positional split are filled by the caller
+    t.kind = 1; t.axis = best_ax; t.bin = best_bin;
+    t.clo = cb[best_ax]; t.scale = pt_sah_scale(cb[best_ax], cb[3 + best_ax]);
+    for (int k = 0; k < 3; ++k) { t.lo0[k] = lo0[k]; t.hi0[k] = hi0[k]; t.lo1[k] = lo1[k]; t.hi1[k] = hi1[k]; }
+}
+
 // Fills the decision fields of `t` from its bins; cb (lo[3], hi[3]) is the interval the bins span.
 PT_HD static inline void pt_sah_decide(PtSahTask& t, const PtSahBinsF& B, const float cb[6], uint32_t max_leaf)
 {
@@ -76,19 +93,15 @@ PT_HD static inline void pt_sah_decide(PtSahTask& t, const PtSahBinsF& B, const 
             }
         }
     }
-    const bool have = best_ax >= 0;
-    const bool can_leaf = t.parent >= 0 && n <= max_leaf;
-    const float A = pt_sah_area(t.lo, t.hi);
-    if (n == 1 || (can_leaf && (!have || (float)n * A <= A + best))) { t.kind = 0; return; }
-    if (!have) { t.kind = 2; return; }            // child boxes of a positional split are filled by the caller
-    t.kind = 1; t.axis = best_ax; t.bin = best_bin;
-    t.clo = cb[best_ax]; t.scale = pt_sah_scale(cb[best_ax], cb[3 + best_ax]);
-    for (int k = 0; k < 3; ++k) { t.lo0[k] = inf; t.hi0[k] = -inf; t.lo1[k] = inf; t.hi1[k] = -inf; }
-    for (int q = 0; q < PT_SAH_BINS; ++q) {
-        if (B.cnt[best_ax][q] == 0) continue;
-        float* lo = q <= best_bin ? t.lo0 : t.lo1; float* hi = q <= best_bin ? t.hi0 : t.hi1;
-        for (int k = 0; k < 3; ++k) { lo[k] = fminf(lo[k], B.lo[best_ax][q][k]); hi[k] = fmaxf(hi[k], B.hi[best_ax][q][k]); }
-    }
+    float lo0[3], hi0[3], lo1[3], hi1[3];
+    for (int k = 0; k < 3; ++k) { lo0[k] = inf; hi0[k] = -inf; lo1[k] = inf; hi1[k] = -inf; }
+    if (best_ax >= 0)
+        for (int q = 0; q < PT_SAH_BINS; ++q) {
+            if (B.cnt[best_ax][q] == 0) continue;
+            float* lo = q <= best_bin ? lo0 : lo1; float* hi = q <= best_bin ? hi0 : hi1;
+            for (int k = 0; k < 3; ++k) { lo[k] = fminf(lo[k], B.lo[best_ax][q][k]); hi[k] = fmaxf(hi[k], B.hi[best_ax][q][k]); }
+        }
+    pt_sah_finish(t, best_ax, best_bin, best, lo0, hi0, lo1, hi1, cb, max_leaf);
 }
 
 // true: the primitive at position i goes to the left child of the split range t
