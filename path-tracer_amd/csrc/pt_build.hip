@@ -673,6 +673,20 @@ struct DevMem {
     }
 };
 
+// One word back from the device: through the context's pinned word, so the copy is a DMA and not a
+// staged pageable copy (the builders do this once per tree level).
+hipError_t read_word(PtContext* ctx, const uint32_t* dev, uint32_t* out)
+{
+    if (!ctx->pinned_word) {
+        hipError_t e = hipHostMalloc((void**)&ctx->pinned_word, 64, hipHostMallocDefault);
+        if (e != hipSuccess) return e;
+    }
+    hipError_t e = hipMemcpyAsync(ctx->pinned_word, dev, 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) *out = *ctx->pinned_word;
+    return e;
+}
+
 int scan_exclusive(hipStream_t st, DevMem& mem, const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* total_dev, uint32_t* sums = nullptr)
 {
     uint32_t nb = div_up(n, kBlock);
@@ -741,7 +755,7 @@ int pt_build_sah(PtContext* ctx, const float* boxes, uint32_t n, uint32_t max_le
         int rc = scan_exclusive(st, mem, inner, offsets, m, total, sums);
         if (rc) return rc;
         uint32_t n_inner = 0;
-        if (hipMemcpyAsync(&n_inner, total, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+        if (read_word(ctx, total, &n_inner) != hipSuccess) {
             pt_set_error("pt_build_sah: %s", hipGetErrorString(hipGetLastError())); return PT_ERROR_HIP;
         }
         k_sah_emit<<<div_up(m, kBlock), kBlock, 0, st>>>(m, tasks_a, offsets, node_base, nodes);
@@ -783,7 +797,7 @@ int pt_build_wide(PtContext* ctx, const PtBvhNode* nodes_dev, uint32_t node_coun
         if (rc) return fail(rc);
         k_wide_emit<<<nb, kBlock, 0, st>>>(nodes_dev, front_a, n_front, offsets, level_base, wide, front_b);
         uint32_t next = 0;
-        if (hipMemcpyAsync(&next, total, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+        if (read_word(ctx, total, &next) != hipSuccess) {
             pt_set_error("pt_build_wide: %s", hipGetErrorString(hipGetLastError())); return fail(PT_ERROR_HIP);
         }
         level_base += n_front; n_front = next;
@@ -854,7 +868,7 @@ int pt_build_lbvh(PtContext* ctx, const float* boxes, uint32_t n, uint32_t max_l
     while (finished < (uint32_t)ni) {
         for (int k = 0; k < 8; ++k, ++pass)
             k_refit_pass<<<nbi, kBlock, 0, st>>>(ni, pass, left, right, boxes, vals, data, collapsed, done, max_leaf, n_done);
-        if (hipMemcpyAsync(&finished, n_done, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+        if (read_word(ctx, n_done, &finished) != hipSuccess) {
             pt_set_error("pt_build_lbvh: refit failed: %s", hipGetErrorString(hipGetLastError())); return fail(PT_ERROR_HIP);
         }
         if (pass > 4096) { pt_set_error("pt_build_lbvh: refit did not converge"); return fail(PT_ERROR_HIP); }
@@ -863,7 +877,7 @@ int pt_build_lbvh(PtContext* ctx, const float* boxes, uint32_t n, uint32_t max_l
     rc = scan_exclusive(st, mem, alive, new_index, (uint32_t)ni, total);
     if (rc) return fail(rc);
     uint32_t n_alive = 0;
-    if (hipMemcpyAsync(&n_alive, total, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+    if (read_word(ctx, total, &n_alive) != hipSuccess) {
         pt_set_error("pt_build_lbvh: scan failed: %s", hipGetErrorString(hipGetLastError())); return fail(PT_ERROR_HIP);
     }
     if (hipMalloc((void**)&nodes, sizeof(PtBvhNode) * (size_t)n_alive) != hipSuccess) { pt_set_error("pt_build_lbvh: out of memory"); return fail(PT_ERROR_OUT_OF_MEMORY); }

@@ -137,6 +137,7 @@ int pt_ctx_destroy(PtContext* c)
     (void)hipFree(c->materials); (void)hipFree(c->geometry_nodes); (void)hipFree(c->blas_instances); (void)hipFree(c->textures);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     for (auto& ch : c->build_arena.chunks) (void)hipFree(ch.first);
+    if (c->pinned_word) (void)hipHostFree(c->pinned_word);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return PT_OK;

@@ -156,6 +156,7 @@ struct PtContext {
     size_t ev_used = 0;
     std::vector<uint8_t> ev_primary;           // per pair: the launch was bounce 0 (k_primary)
     PtArena build_arena;
+    uint32_t* pinned_word = nullptr;           // pinned host word for single-value readbacks
     std::vector<uint32_t> ev_depth;            // depth of each recorded pair
     uint64_t stats_mark[PT_MAX_DEPTH] = {};    // rays_per_depth at the last pt_trace_profile
 };
