@@ -38,6 +38,9 @@
 #ifndef PT_SCHED_NODE_STEPS
 #define PT_SCHED_NODE_STEPS 6      // box steps per vote while at least half the wave takes part
 #endif
+#ifndef PT_SCHED_NODE_STAY
+#define PT_SCHED_NODE_STAY 32      // ... and only while this many lanes still take part
+#endif
 #ifndef PT_SCHED_LEAF_STEPS
 #define PT_SCHED_LEAF_STEPS 4      // triangles per vote while enough lanes take part
 #endif
@@ -193,7 +196,7 @@ __device__ __forceinline__ void pt_traverse_sched(const PtTlasView& tl, const Pt
                     want_node = (unsigned)node < (unsigned)PT_NODE_DONE;
                 }
                 n_node = __popcll(__ballot(want_node));
-            } while (--steps > 0 && n_node >= 32);
+            } while (--steps > 0 && n_node >= PT_SCHED_NODE_STAY);
         } else if (phase == 1) {
             int steps = PT_SCHED_LEAF_STEPS;
             do {
