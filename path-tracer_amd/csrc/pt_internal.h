@@ -122,10 +122,10 @@ struct PtWorkspace {                   // shared by all lanes
 
 // Per-lane traversal stack capacity: entries in LDS, then entries in a per-thread global slice.
 #ifndef PT_LDS_STACK
-#define PT_LDS_STACK 24
+#define PT_LDS_STACK 16
 #endif
 #ifndef PT_SPILL_STACK
-#define PT_SPILL_STACK 104
+#define PT_SPILL_STACK 112
 #endif
 
 struct PtContext {

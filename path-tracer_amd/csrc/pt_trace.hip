@@ -31,7 +31,8 @@
 namespace {
 
 #ifndef PT_INTERSECT_WAVES
-#define PT_INTERSECT_WAVES 4   // waves per SIMD the traversal kernels are compiled for
+#define PT_INTERSECT_WAVES 5   // waves per SIMD k_intersect is compiled for: the scheduled traversal needs 92 registers; the plain
+                               // schedule in the same kernel (short levels only) pays 44 bytes of scratch per lane for it
 #endif
 constexpr int kBlock = 256;
 static_assert(kBlock == PT_TRAVERSE_BLOCK, "traversal stack stride");
@@ -169,7 +170,8 @@ k_intersect(PtTlasView tl, uint32_t* __restrict__ counters, uint32_t depth, uint
             PtHit* __restrict__ hits, float* __restrict__ t_out, int* __restrict__ spill, uint32_t sched_min_rays)
 {
     __shared__ int s_stack[PT_LDS_STACK][kBlock];
-    __shared__ float s_world[12][kBlock];   // scheduled traversal: the world-space ray of a lane inside an instance
+    __shared__ float s_world[6][kBlock];    // scheduled traversal: world-space origin and direction of a lane inside an instance
+    __shared__ int s_cold[6][kBlock];       // ... and its rarely used state (closest hit's ids and barycentrics, queue slot, delta)
     PtStack stk;
     stk.lds = (pt_lds_int*)&s_stack[0][threadIdx.x];
     stk.spill_base = spill;
@@ -179,7 +181,7 @@ k_intersect(PtTlasView tl, uint32_t* __restrict__ counters, uint32_t depth, uint
         PtSchedQueue Q;
         Q.counters = counters; Q.shard_cap = shard_cap; Q.n_shards = kShards; Q.ctr_pad = kCtrPad;
         Q.count_base = ctr_index(CTR_COUNT, depth, 0); Q.work_base = ctr_index(CTR_WORK_INTERSECT, depth, 0);
-        pt_traverse_sched<BY_ID>(tl, Q, stk, (pt_lds_float*)&s_world[0][threadIdx.x], q0, q1, tmin, tmax, hits, t_out);
+        pt_traverse_sched<BY_ID>(tl, Q, stk, (pt_lds_float*)&s_world[0][threadIdx.x], (pt_lds_int*)&s_cold[0][threadIdx.x], q0, q1, tmin, tmax, hits, t_out);
         return;
     }
     for_each_batch<false>(counters, CTR_WORK_INTERSECT, depth, shard_cap, [&](uint32_t i, bool valid, uint32_t shard) {

@@ -13,10 +13,16 @@
 // (b) phase voting: the wave executes ONE phase at a time -- the one its lanes vote for, for a few
 //     steps in a row -- and the other lanes wait, so the long phases (triangle test, instance entry)
 //     only run once enough lanes have accumulated in them.
-// Per-lane state is kept small (one ray space, the best hit, six scalars): the world-space ray waits
-// in LDS (ws: 12 words per lane, [word][thread]) while a lane is inside an instance, and the triangle
-// test rebuilds its axis permutation from the ray, which keeps the kernel within the 128 registers of four waves per SIMD
-// without spills.
+// Registers decide how many waves hide each other's memory latency, and a fifth wave per SIMD is worth
+// 7 % here, so per-lane state that is touched rarely lives in LDS, [word][thread]:
+//   ws    the world-space origin and direction while a lane is inside an instance (its reciprocals are
+//         recomputed on the way out, which half the rays never need: leaving the last instance with
+//         an empty stack ends the ray);
+//   cold  the ids and barycentrics of the closest hit so far (read only on an exact distance tie and
+//         when the ray ends), the ray's queue slot and the instance's delta.
+// In registers remain the current ray space, the closest distance and six scalars; the triangle test
+// rebuilds its axis permutation from the ray and handles one triangle per step (two at once would
+// need four registers too many).  That is 92 registers: five waves per SIMD without spills.
 // The per-lane arithmetic (slab test, gated watertight triangle test, hit ordering) is the one in
 // pt_device.h, so results are bit-identical to the plain traversal.
 #pragma once
@@ -61,13 +67,12 @@ struct PtSchedQueue {              // the sharded queue of one bounce
 };
 
 template <bool BY_ID>
-__device__ __forceinline__ void pt_traverse_sched(const PtTlasView& tl, const PtSchedQueue& Q, PtStack& stk, pt_lds_float* ws,
+__device__ __forceinline__ void pt_traverse_sched(const PtTlasView& tl, const PtSchedQueue& Q, PtStack& stk, pt_lds_float* ws, pt_lds_int* cold,
                                                   const float4* __restrict__ q0, const float4* __restrict__ q1,
                                                   float tmin, float tmax, PtHit* __restrict__ hits, float* __restrict__ t_out)
 {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
     // ---- wave-uniform work cursor.  Lane s looks at shard s once (the queue only shrinks while the
     // kernel runs); shards with work left are the set bits of `avail`, visited round-robin from the
@@ -85,13 +90,13 @@ __device__ __forceinline__ void pt_traverse_sched(const PtTlasView& tl, const Pt
 
     // ---- per-lane traversal state
     PtRaySpace cur;
-    PtHitRec best;
-    float delta = 0.0f, tlo = tmin, thi = tmax;
-    uint32_t cur_inst = PT_NO_INSTANCE, qi = 0;
+    float best_t = tmax;           // distance of the closest hit so far; its ids and barycentrics are in `cold`
+    float tlo = tmin, thi = tmax;
+    uint32_t cur_inst = PT_NO_INSTANCE;
+#define PT_COLD(k) cold[(k) * PT_TRAVERSE_BLOCK]      // 0 instance, 1 primitive, 2 u, 3 v, 4 queue slot, 5 delta
     int node = PT_NODE_DONE;       // PT_NODE_DONE: lane is idle
     stk.sp = 0;
     cur.ox = cur.oy = cur.oz = cur.dx = cur.dy = cur.dz = cur.ix = cur.iy = cur.iz = cur.oox = cur.ooy = cur.ooz = 0.0f;
-    best.t = tmax; best.inst = PT_NO_INSTANCE; best.prim = 0xFFFFFFFFu; best.u = best.v = 0.0f;
 
     // Takes the next item for this lane after the current one is exhausted: pops until an inner node,
     // a leaf or the end of the ray comes up; leaving an instance restores the world-space ray.
@@ -101,20 +106,19 @@ __device__ __forceinline__ void pt_traverse_sched(const PtTlasView& tl, const Pt
                 // nothing left above the instance: the ray is finished, its world-space form is not needed
                 if (stk.sp == 0) { v = PT_NODE_DONE; continue; }
                 // a few lanes at a time get here, so this must not wait for global memory or divide
-                cur.ox = ws[0 * PT_TRAVERSE_BLOCK]; cur.oy = ws[1 * PT_TRAVERSE_BLOCK]; cur.oz = ws[2 * PT_TRAVERSE_BLOCK];
-                cur.dx = ws[3 * PT_TRAVERSE_BLOCK]; cur.dy = ws[4 * PT_TRAVERSE_BLOCK]; cur.dz = ws[5 * PT_TRAVERSE_BLOCK];
-                cur.ix = ws[6 * PT_TRAVERSE_BLOCK]; cur.iy = ws[7 * PT_TRAVERSE_BLOCK]; cur.iz = ws[8 * PT_TRAVERSE_BLOCK];
-                cur.oox = ws[9 * PT_TRAVERSE_BLOCK]; cur.ooy = ws[10 * PT_TRAVERSE_BLOCK]; cur.ooz = ws[11 * PT_TRAVERSE_BLOCK];
+                pt_ray_space_init(cur, ws[0 * PT_TRAVERSE_BLOCK], ws[1 * PT_TRAVERSE_BLOCK], ws[2 * PT_TRAVERSE_BLOCK],
+                                  ws[3 * PT_TRAVERSE_BLOCK], ws[4 * PT_TRAVERSE_BLOCK], ws[5 * PT_TRAVERSE_BLOCK]);
                 cur_inst = PT_NO_INSTANCE; tlo = tmin; thi = tmax;
                 v = stk.pop();
                 continue;
             }
             if (v == PT_NODE_DONE) {
-                PtHit out; out.instance = best.inst; out.primitive = best.prim; out.u = best.u; out.v = best.v;
+                const uint32_t qi = (uint32_t)PT_COLD(4);
+                PtHit out; out.instance = (uint32_t)PT_COLD(0); out.primitive = (uint32_t)PT_COLD(1); out.u = __int_as_float(PT_COLD(2)); out.v = __int_as_float(PT_COLD(3));
                 const uint32_t dst = BY_ID ? __float_as_uint(q1[qi].w) : qi;
                 if (BY_ID) hits[dst] = out;     // the caller's array: no alignment beyond the record's own
                 else pt_stream_store((float4*)&hits[dst], make_float4(__uint_as_float(out.instance), __uint_as_float(out.primitive), out.u, out.v));
-                if (BY_ID && t_out) t_out[dst] = best.t;
+                if (BY_ID && t_out) t_out[dst] = best_t;
             }
             node = v;
             return;
@@ -150,17 +154,16 @@ __device__ __forceinline__ void pt_traverse_sched(const PtTlasView& tl, const Pt
                 }
                 const uint32_t n_idle = __popcll(idle), left = wend - wcur;
                 const uint32_t take = n_idle < left ? n_idle : left;
-                const uint32_t rank = __popcll(idle & lt_mask);
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));   // set bits of idle below this lane
                 if (node == PT_NODE_DONE && rank < take) {
-                    qi = wcur + rank;
-                    const float4 o = pt_stream_load(&q0[qi]), d = pt_stream_load(&q1[qi]);
+                    const uint32_t slot = wcur + rank;
+                    PT_COLD(4) = (int)slot; PT_COLD(0) = (int)PT_NO_INSTANCE; PT_COLD(1) = -1; PT_COLD(2) = 0; PT_COLD(3) = 0;
+                    const float4 o = pt_stream_load(&q0[slot]), d = pt_stream_load(&q1[slot]);
                     pt_ray_space_init(cur, o.x, o.y, o.z, d.x, d.y, d.z);
                     ws[0 * PT_TRAVERSE_BLOCK] = cur.ox; ws[1 * PT_TRAVERSE_BLOCK] = cur.oy; ws[2 * PT_TRAVERSE_BLOCK] = cur.oz;
                     ws[3 * PT_TRAVERSE_BLOCK] = cur.dx; ws[4 * PT_TRAVERSE_BLOCK] = cur.dy; ws[5 * PT_TRAVERSE_BLOCK] = cur.dz;
-                    ws[6 * PT_TRAVERSE_BLOCK] = cur.ix; ws[7 * PT_TRAVERSE_BLOCK] = cur.iy; ws[8 * PT_TRAVERSE_BLOCK] = cur.iz;
-                    ws[9 * PT_TRAVERSE_BLOCK] = cur.oox; ws[10 * PT_TRAVERSE_BLOCK] = cur.ooy; ws[11 * PT_TRAVERSE_BLOCK] = cur.ooz;
                     cur_inst = PT_NO_INSTANCE; tlo = tmin; thi = tmax;
-                    best.t = tmax; best.inst = PT_NO_INSTANCE; best.prim = 0xFFFFFFFFu; best.u = best.v = 0.0f;
+                    best_t = tmax;
                     stk.sp = 0;
                     node = 0;
                 }
@@ -191,7 +194,7 @@ __device__ __forceinline__ void pt_traverse_sched(const PtTlasView& tl, const Pt
             do {
                 { const int act_ = __popcll(__ballot(want_node)); (void)act_; PT_STAT(0, 1); PT_STAT(3, act_); }
                 if (want_node) {
-                    const int next = pt_wide_step(cur, tl.nodes, node, tlo, fminf(thi, best.t), stk);
+                    const int next = pt_wide_step(cur, tl.nodes, node, tlo, fminf(thi, best_t), stk);
                     if ((unsigned)next < (unsigned)PT_NODE_DONE) node = next; else advance(next);
                     want_node = (unsigned)node < (unsigned)PT_NODE_DONE;
                 }
@@ -202,28 +205,26 @@ __device__ __forceinline__ void pt_traverse_sched(const PtTlasView& tl, const Pt
             do {
                 { const int act_ = __popcll(__ballot(want_leaf)); (void)act_; PT_STAT(1, 1); PT_STAT(4, act_); }
                 if (want_leaf) {
-                    // up to two triangles of the leaf per step: both are requested at once, so a
-                    // two-triangle leaf (a quad) costs one memory round trip, not two
                     const uint32_t code = ~(uint32_t)node;
                     const uint32_t pos = code >> 3;
-                    const bool two = (code & 7u) != 0u;
                     const float4 a = tl.tris[3 * (size_t)pos + 0], b = tl.tris[3 * (size_t)pos + 1], c = tl.tris[3 * (size_t)pos + 2];
-                    float4 a2 = a, b2 = b, c2 = c;
-                    if (two) { a2 = tl.tris[3 * (size_t)pos + 3]; b2 = tl.tris[3 * (size_t)pos + 4]; c2 = tl.tris[3 * (size_t)pos + 5]; }
+                    const float delta = __int_as_float(PT_COLD(5));
                     float t, u, v;
                     if (pt_tri_test(cur, delta, a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, t, u, v)) {
                         const uint32_t prim = __float_as_uint(c.y);
-                        if (t > tmin && t < tmax && t >= tlo && t <= thi)
-                            pt_hit_update(best, t, cur_inst, prim, u, v);
+                        if (t > tmin && t < tmax && t >= tlo && t <= thi) {
+                            // the order of pt_hit_update; the ids are only looked at on an exact tie
+                            bool closer = t < best_t;
+                            if (t == best_t) {
+                                const unsigned long long id = ((unsigned long long)cur_inst << 32) | prim;
+                                const unsigned long long best_id = ((unsigned long long)(uint32_t)PT_COLD(0) << 32) | (uint32_t)PT_COLD(1);
+                                closer = id < best_id;
+                            }
+                            if (closer) { best_t = t; PT_COLD(0) = (int)cur_inst; PT_COLD(1) = (int)prim; PT_COLD(2) = __float_as_int(u); PT_COLD(3) = __float_as_int(v); }
+                        }
                     }
-                    if (two && pt_tri_test(cur, delta, a2.x, a2.y, a2.z, a2.w, b2.x, b2.y, b2.z, b2.w, c2.x, t, u, v)) {
-                        const uint32_t prim = __float_as_uint(c2.y);
-                        if (t > tmin && t < tmax && t >= tlo && t <= thi)
-                            pt_hit_update(best, t, cur_inst, prim, u, v);
-                    }
-                    // first + done, count - done
-                    const uint32_t done = two ? 2u : 1u;
-                    if ((code & 7u) >= done) node = (int)~(code + 7u * done);
+                    // one triangle per step: first + 1, count - 1
+                    if (code & 7u) node = (int)~(code + 7u);
                     else advance(stk.pop());
                     want_leaf = node < 0 && cur_inst != PT_NO_INSTANCE;
                 }
@@ -237,14 +238,14 @@ __device__ __forceinline__ void pt_traverse_sched(const PtTlasView& tl, const Pt
                 const float4 r0 = q[0], r1 = q[1], r2 = q[2], blo = q[3], bhi = q[4], misc = q[5];
                 float a, b;
                 pt_slab(cur, blo.x, blo.y, blo.z, bhi.x, bhi.y, bhi.z, a, b);
-                bool enter = (a <= b) && !(b < tmin) && !(a > tmax) && !(a > best.t);
+                bool enter = (a <= b) && !(b < tmin) && !(a > tmax) && !(a > best_t);
                 if (enter) {
                     float oox, ooy, ooz, odx, ody, odz;
                     pt_to_object_space(r0, r1, r2, cur, oox, ooy, ooz, odx, ody, odz);
                     enter = pt_ray_valid(odx, ody, odz);
                     if (enter) {
                         pt_ray_space_init(cur, oox, ooy, ooz, odx, ody, odz);
-                        delta = blo.w;
+                        PT_COLD(5) = __float_as_int(blo.w);
                         cur_inst = __float_as_uint(misc.y);
                         tlo = fmaxf(tmin, a); thi = fminf(tmax, b);
                         stk.push(PT_NODE_SENTINEL);
