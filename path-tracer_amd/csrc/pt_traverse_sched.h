@@ -30,7 +30,7 @@
 
 #define PT_SCHED_CHUNK 256u        // most queue slots a wave claims per atomic (fewer when the queue is short)
 #ifndef PT_SCHED_REFILL
-#define PT_SCHED_REFILL 12         // refill when at least this many lanes are idle
+#define PT_SCHED_REFILL 24         // refill when at least this many lanes are idle (five waves per SIMD cover for the idle lanes)
 #endif
 #ifndef PT_SCHED_LEAF_VOTES
 #define PT_SCHED_LEAF_VOTES 20     // run the triangle phase once this many lanes wait in it ...
