@@ -5,7 +5,8 @@
 
 One step = one pt_trace call of --spp samples per pixel over the whole 1920x1080 image of the
 dragon scene (procedural stand-in for the missing DragonAttenuation.bin), all inputs resident in
-HBM; --frames-in-flight steps may overlap on the library's internal streams (default here: 1).
+HBM; --frames-in-flight steps may overlap on the library's internal streams (default here: 2, the
+library's own default is 3).
 With N > 1 (one process per GPU under torch.distributed.run) rank r renders frames
 r, r+N, r+2N, ... (samples-per-pixel sharding) into its own float sum buffer and the buffers are
 summed with one RCCL all-reduce inside the timed region; per-GPU work is fixed, so scaling is weak.
@@ -84,9 +85,14 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=64, help="samples per pixel per step (one pt_trace call)")
     ap.add_argument("--max-depth", type=int, default=10)
-    ap.add_argument("--frames-in-flight", type=int, default=1,
-                    help="steps the library keeps in flight on separate streams (library default 3: worth +9 %% at 16 spp per step, "
-                         "nothing at 64, where one step fills the GPU; 1 keeps every launch's event timing exclusive)")
+    ap.add_argument("--frames-in-flight", type=int, default=2,
+                    help="steps the library keeps in flight on separate streams (library default 3). With two, the shading and "
+                         "bounce-0 kernels of one step overlap the traversal of the other: +5.6 %% at 64 spp per step. Launches "
+                         "that share the GPU last longer than they would alone: --frames-in-flight 1 (or --serial-roofline) gives "
+                         "the kernels' exclusive durations")
+    ap.add_argument("--serial-roofline", action="store_true",
+                    help="after the timed region, repeat three steps with one frame in flight and report their kernel durations as "
+                         "roofline.one_frame_at_a_time (extra launches: keep it out of profiled runs; --frames-in-flight 1 measures the same)")
     ap.add_argument("--cpu-spp", type=int, default=16, help="samples per pixel of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--secondary", action="store_true", help="also measure the cornell scene (extra launches: keep it out of profiled runs)")
@@ -163,7 +169,7 @@ def main():
     frames_seen = float(accum.view(-1, 4)[0, 3])
     # the same kernel with one frame at a time, so that a launch has the GPU to itself (not part of `value`)
     prof_serial = None
-    if rank == 0 and args.frames_in_flight > 1:
+    if rank == 0 and args.frames_in_flight > 1 and args.serial_roofline:
         r.ctx.set_frames_in_flight(1)
         run_steps(r, accum.data_ptr(), 1, 3_000_000, 0, 1, args.spp, args.max_depth)
         r.profile()
@@ -207,7 +213,7 @@ def main():
         out["roofline"] = {
             "bound": "hbm", "kernel": "k_intersect + k_primary", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": measured_traffic(f"{args.scene} {W}x{H} {args.spp}spp depth{args.max_depth} lanes{args.frames_in_flight}"),
+            "traffic": measured_traffic(f"{args.scene} {W}x{H} {args.spp}spp depth{args.max_depth}"),
             "launches": i_n, "avg_launch_ms": i_ms / max(i_n, 1), "rays_per_launch": i_rays / max(i_n, 1),
             "frames_in_flight": args.frames_in_flight,
             "bytes_per_ray": bytes_intersect, "box_tests_per_ray": vn, "tri_tests_per_ray": vt,
