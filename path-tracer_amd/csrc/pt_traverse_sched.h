@@ -28,7 +28,9 @@
 #pragma once
 #include "pt_device.h"
 
+#ifndef PT_SCHED_CHUNK
 #define PT_SCHED_CHUNK 256u        // most queue slots a wave claims per atomic (fewer when the queue is short)
+#endif
 #ifndef PT_SCHED_REFILL
 #define PT_SCHED_REFILL 24         // refill when at least this many lanes are idle (five waves per SIMD cover for the idle lanes)
 #endif
