@@ -47,18 +47,23 @@ __host__ __device__ inline size_t ctr_index(int kind, uint32_t depth, uint32_t s
     return ((size_t)kind * kCtrPerKind + (size_t)depth * kShards + shard) * kCtrPad;
 }
 
-// Batches of 64 paths are dealt round-robin to the shards; the partial last batch is the last
-// batch of its shard, so every shard is dense.
-__device__ __forceinline__ uint32_t slot_of_path(uint32_t q, uint32_t shard_cap)
+// Groups of PT_DEAL_GROUP consecutive batches of 64 paths are dealt round-robin to the shards, so
+// neighbouring batches (neighbouring pixels) sit next to each other in a shard and a wave's chunk holds
+// rays that start close together; the partial last group is the last of its shard, so every shard is dense.
+#ifndef PT_DEAL_GROUP
+#define PT_DEAL_GROUP 4u
+#endif
+constexpr uint32_t kDealPaths = PT_DEAL_GROUP * 64u;
+__host__ __device__ inline uint32_t slot_of_path(uint32_t q, uint32_t shard_cap)
 {
-    const uint32_t batch = q >> 6;
-    return (batch % kShards) * shard_cap + (batch / kShards) * 64u + (q & 63u);
+    const uint32_t g = q / kDealPaths;
+    return (g % kShards) * shard_cap + (g / kShards) * kDealPaths + q % kDealPaths;
 }
-__device__ __forceinline__ uint32_t shard_count(uint32_t n, uint32_t s)
+__host__ __device__ inline uint32_t shard_count(uint32_t n, uint32_t s)
 {
-    const uint32_t fb = n >> 6, rem = n & 63u;
-    uint32_t c = (fb / kShards + (s < fb % kShards ? 1u : 0u)) * 64u;
-    if (rem && (fb % kShards) == s) c += rem;
+    const uint32_t full = n / kDealPaths, rem = n % kDealPaths;
+    uint32_t c = (full / kShards + (s < full % kShards ? 1u : 0u)) * kDealPaths;
+    if (rem && (full % kShards) == s) c += rem;
     return c;
 }
 
@@ -115,7 +120,7 @@ struct PtPrimaryArg {
 __device__ __forceinline__ uint32_t path_of_slot(uint32_t slot, uint32_t s, uint32_t shard_cap)
 {
     const uint32_t within = slot - s * shard_cap;
-    return (((within >> 6) * kShards + s) << 6) + (within & 63u);
+    return ((within / kDealPaths) * kShards + s) * kDealPaths + within % kDealPaths;
 }
 
 // ray_gen.rgen:21-31: origin and direction of the primary ray of path q
@@ -613,8 +618,8 @@ int ensure_workspace(PtContext* ctx, PtLane& l, uint64_t paths, uint64_t pixels)
         PT_HIP_CHECK(hipMalloc((void**)&l.spill, sizeof(int) * PT_SPILL_STACK * w.spill_threads));
     }
     // per-shard capacity: the batches dealt to one shard, in slots
-    const uint64_t batches = (paths + 63) / 64;
-    const uint64_t cap = ((batches + kShards - 1) / kShards) * 64;
+    const uint64_t groups = (paths + kDealPaths - 1) / kDealPaths;
+    const uint64_t cap = ((groups + kShards - 1) / kShards) * kDealPaths;
     if (cap > l.shard_cap) {
         PT_HIP_CHECK(hipStreamSynchronize(l.stream));   // earlier work of this lane still uses the old queues
         for (int a = 0; a < 2; ++a) for (int k = 0; k < 4; ++k) { (void)hipFree(l.q[a][k]); l.q[a][k] = nullptr; }
