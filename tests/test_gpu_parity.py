@@ -372,3 +372,28 @@ def test_shading_follows_the_geometry_nodes_buffers():
         assert _float_eq(r.last_result(), want_mirrored)
     finally:
         r.close()
+
+
+def test_trace_profile_accounts_for_every_launch(cornell):
+    """With profiling on, every traversal launch is timed once: one k_primary per frame, one k_intersect
+    per later bounce, and their ray counts add up to the frame statistics; results are unchanged."""
+    w = h = 64
+    a = _renderer(cornell, w, h)
+    b = _renderer(cornell, w, h)
+    try:
+        b.set_profiling(True)
+        for frame in range(3):
+            a.render(spp=8, max_depth=6, frame=frame)
+            b.render(spp=8, max_depth=6, frame=frame)
+        assert _float_eq(a.accum_host(), b.accum_host())
+        p, st = b.profile(), b.stats()
+        assert int(p["primary_launches"]) == 3 and int(p["intersect_launches"]) == 3 * 5
+        assert int(p["primary_rays"]) == 3 * w * h * 8 == int(st["rays_per_depth"][0])
+        assert int(p["primary_rays"]) + int(p["intersect_rays"]) == int(st["rays"])
+        assert float(p["primary_ms"]) > 0.0 and float(p["intersect_ms"]) > 0.0
+        # the pairs are consumed: a second call reports nothing new
+        q = b.profile()
+        assert int(q["primary_launches"]) == 0 and int(q["intersect_launches"]) == 0 and int(q["intersect_rays"]) == 0
+    finally:
+        a.close()
+        b.close()
