@@ -329,6 +329,28 @@ def test_full_size_properties_1080p(dragon):
         r.close()
 
 
+def test_full_size_step_in_one_chunk_equals_pixel_chunks(dragon):
+    """The benchmark's step (1080p x 256 spp = 531 M paths resident at once, slot indices beyond 2^29)
+    gives, bit for bit, the frame and the ray counts of the same step traced in pixel chunks of
+    2^27 paths."""
+    w, h, spp = 1920, 1080, 256
+    got = {}
+    for name, max_paths in (("one", w * h * spp), ("chunks", 1 << 27)):
+        r = _renderer(dragon, w, h)
+        try:
+            r.ctx.set_frames_in_flight(1)
+            r.ctx.set_max_paths(max_paths)
+            r.render(spp=spp, frame=5)
+            s = r.stats()
+            assert int(s["paths"]) == w * h * spp
+            got[name] = (r.last_result().copy(), s["rays_per_depth"].astype(np.int64).copy())
+        finally:
+            r.close()
+    assert _float_eq(got["one"][0], got["chunks"][0])
+    assert np.array_equal(got["one"][1], got["chunks"][1])
+    assert np.isfinite(got["one"][0]).all()
+
+
 def test_errors_are_reported(cornell):
     from pt_amd import hip
     r = _renderer(cornell, 16, 16)

@@ -59,5 +59,6 @@ def test_default_line_is_there_with_its_cpu_baseline():
     j = _line(default[0])
     assert "cpu_baseline" in j and j["n_gpus"] == 1
     t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-    key = "dragon 1920x1080 64spp depth10"
+    m = re.match(r"(\w+) (\d+x\d+), (\d+) spp per step, max depth (\d+)", j["config"]["workload"])
+    key = f"{m.group(1)} {m.group(2)} {m.group(3)}spp depth{m.group(4)}"
     assert key in t and abs(t[key]["bytes_per_launch"] - j["roofline"]["traffic"]) < 1.0
