@@ -38,6 +38,26 @@ def measured_traffic(workload_key):
         return None
 
 
+def valu_issue(workload_key, avg_launch_ms, n_simds):
+    """Vector-instruction issue rate of the traversal launches: wave64 vector instructions per launch
+    (SQ_INSTS_VALU of this workload, profiles/traffic.json) over the launches' average duration measured
+    in this run, per SIMD and 2.4 GHz cycle.  The ceilings are what one SIMD issues of a single
+    instruction kind with 2-8 waves (tools/micro/valu_rate.hip): 0.40 for the full-rate kind (fma, add, mul,
+    and/or/xor, mov), 0.235 for the half-rate kind (cndmask, min/max, compares, conversions), of which
+    a traversal step is two thirds.  With several frames in flight the launches share the GPU and
+    the rate per launch is lower by the stretch."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            rec = json.load(f).get(workload_key)
+        n = float(rec["valu_insts_per_launch"])
+    except (OSError, ValueError, KeyError, TypeError):
+        return None
+    if avg_launch_ms <= 0:
+        return None
+    return {"insts_per_cycle_per_simd": n / (avg_launch_ms * 1e-3 * n_simds * 2.4e9), "valu_insts_per_launch": n,
+            "simds": n_simds, "clock_ghz": 2.4, "ceiling_half_rate_kind": 0.235, "ceiling_full_rate_kind": 0.40}
+
+
 def build_scene(name):
     from pt_amd import procedural
     from pt_amd.scene import Scene
@@ -96,9 +116,11 @@ def main():
                          "bounce-0 kernels of one step overlap the traversal of the other: +5.6 %% at 64 spp per step. Launches "
                          "that share the GPU last longer than they would alone: --frames-in-flight 1 (or --serial-roofline) gives "
                          "the kernels' exclusive durations")
-    ap.add_argument("--serial-roofline", action="store_true",
-                    help="after the timed region, repeat three steps with one frame in flight and report their kernel durations as "
-                         "roofline.one_frame_at_a_time (extra launches: keep it out of profiled runs; --frames-in-flight 1 measures the same)")
+    ap.add_argument("--serial-roofline", action="store_true", help="accepted for older command lines; on by default at one GPU")
+    ap.add_argument("--no-serial-roofline", action="store_true",
+                    help="skip the three steps with one frame in flight that follow the timed region at one GPU (their kernel durations, "
+                         "each launch alone on the GPU, are reported as roofline.one_frame_at_a_time and are not part of `value`); "
+                         "for profiled runs, whose kernel statistics should hold the timed command's launches only")
     ap.add_argument("--cpu-spp", type=int, default=16, help="samples per pixel of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--secondary", action="store_true", help="also measure the cornell scene (extra launches: keep it out of profiled runs)")
@@ -194,7 +216,7 @@ def main():
     frames_seen = float(accum.view(-1, 4)[0, 3])
     # the same kernel with one frame at a time, so that a launch has the GPU to itself (not part of `value`)
     prof_serial = None
-    if rank == 0 and args.frames_in_flight > 1 and args.serial_roofline:
+    if rank == 0 and world == 1 and args.frames_in_flight > 1 and not args.no_serial_roofline:
         r.ctx.set_frames_in_flight(1)
         run_steps(r, accum.data_ptr(), 1, 3_000_000, 0, 1, args.spp, args.max_depth)
         r.profile()
@@ -253,6 +275,11 @@ def main():
             "pipeline_bytes_per_ray": bytes_pipeline,
             "pipeline_frac": (rays / elapsed / world) * bytes_pipeline / 1e9 / HBM_PEAK_GBS,
         }
+        wkey = f"{args.scene} {W}x{H} {args.spp}spp depth{args.max_depth}"
+        n_simds = 4 * torch.cuda.get_device_properties(local_rank).multi_processor_count
+        vi = valu_issue(wkey, i_ms / max(i_n, 1), n_simds)
+        if vi is not None:
+            out["roofline"]["valu_issue"] = vi
         if prof_serial is not None and float(prof_serial["intersect_ms"]) > 0:
             s_ms = float(prof_serial["intersect_ms"]) + float(prof_serial["primary_ms"])
             s_rays = float(prof_serial["intersect_rays"]) + float(prof_serial["primary_rays"])
@@ -262,6 +289,9 @@ def main():
             # same measurement with frames strictly one after the other
             out["roofline"]["one_frame_at_a_time"] = {"achieved": s_ach, "frac": s_ach / HBM_PEAK_GBS, "launches": s_n,
                                                       "avg_launch_ms": s_ms / max(s_n, 1), "intersect_rays_per_s": s_rays / (s_ms * 1e-3)}
+            vs = valu_issue(wkey, s_ms / max(s_n, 1), n_simds)
+            if vs is not None:
+                out["roofline"]["one_frame_at_a_time"]["valu_issue"] = vs
         if world == 1 and args.secondary and not args.no_secondary and args.scene == "dragon":
             r.close()
             c = hip.Renderer(build_scene("cornell"), W, H, device=local_rank, stream=stream)

@@ -16,7 +16,7 @@ for ctrs in \
   "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum TCP_TCC_WRITE_REQ_sum" \
   ; do
   i=$((i+1))
-  timeout -s KILL 120 rocprofv3 --pmc $ctrs --output-format csv -d "$out/pass$i" -- python3 bench.py --no-cpu-baseline --no-secondary "$@" > "$out/pass$i.log" 2>&1
+  timeout -s KILL 120 rocprofv3 --pmc $ctrs --output-format csv -d "$out/pass$i" -- python3 bench.py --no-cpu-baseline --no-secondary --no-serial-roofline "$@" > "$out/pass$i.log" 2>&1
   rc=$?
   echo "pass $i ($ctrs): rc=$rc"
   if [ $rc -ne 0 ]; then tail -3 "$out/pass$i.log"; fi

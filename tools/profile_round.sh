@@ -10,7 +10,7 @@ mkdir -p $out
 timeout -k 10 400 python3 bench.py > $out/bench.json 2> $out/bench.err || { tail -5 $out/bench.err; exit 1; }
 tail -c 600 $out/bench.json; echo
 timeout -k 10 400 python3 bench.py --scene cornell > $out/bench_cornell.json 2> $out/bench_cornell.err || { tail -5 $out/bench_cornell.err; exit 1; }
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py > $out/trace_bench.json 2> $out/trace.err || { tail -5 $out/trace.err; exit 1; }
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --no-serial-roofline > $out/trace_bench.json 2> $out/trace.err || { tail -5 $out/trace.err; exit 1; }
 cp $(ls $out/trace/*/*kernel_stats.csv | head -1) $out/kernel_stats.csv
 # the same with one frame in flight: every launch has the GPU to itself
 timeout -k 10 400 python3 bench.py --frames-in-flight 1 --no-cpu-baseline > $out/bench_serial.json 2> $out/bench_serial.err || { tail -5 $out/bench_serial.err; exit 1; }
