@@ -15,6 +15,7 @@ void pt_set_error(const char* fmt, ...);
     do {                                                                                     \
         hipError_t e_ = (expr);                                                              \
         if (e_ != hipSuccess) {                                                              \
+            (void)hipGetLastError();   /* reported here: a later hipGetLastError() must not see it again */ \
             pt_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
             return e_ == hipErrorOutOfMemory ? PT_ERROR_OUT_OF_MEMORY : PT_ERROR_HIP;        \
         }                                                                                    \
