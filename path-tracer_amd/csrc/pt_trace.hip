@@ -175,7 +175,7 @@ k_intersect(PtTlasView tl, uint32_t* __restrict__ counters, uint32_t depth, uint
             PtHit* __restrict__ hits, float* __restrict__ t_out, int* __restrict__ spill, uint32_t sched_min_rays)
 {
     __shared__ int s_stack[PT_LDS_STACK][kBlock];
-    __shared__ float s_world[6][kBlock];    // scheduled traversal: world-space origin and direction of a lane inside an instance
+    __shared__ float s_world[9][kBlock];    // scheduled traversal: world-space origin, direction and reciprocals of a lane inside an instance
     __shared__ int s_cold[6][kBlock];       // ... and its rarely used state (closest hit's ids and barycentrics, queue slot, delta)
     PtStack stk;
     stk.lds = (pt_lds_int*)&s_stack[0][threadIdx.x];

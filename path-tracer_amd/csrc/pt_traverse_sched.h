@@ -15,9 +15,10 @@
 //     only run once enough lanes have accumulated in them.
 // Registers decide how many waves hide each other's memory latency, and a fifth wave per SIMD is worth
 // 7 % here, so per-lane state that is touched rarely lives in LDS, [word][thread]:
-//   ws    the world-space origin and direction while a lane is inside an instance (its reciprocals are
-//         recomputed on the way out, which half the rays never need: leaving the last instance with
-//         an empty stack ends the ray);
+//   ws    the world-space origin, direction and reciprocals while a lane is inside an instance (leaving
+//         the last instance with an empty stack ends the ray without reading them; otherwise the few
+//         lanes that leave read them back, which costs the wave nine LDS loads and three products
+//         instead of three divisions);
 //   cold  the ids and barycentrics of the closest hit so far (read only on an exact distance tie and
 //         when the ray ends), the ray's queue slot and the instance's delta.
 // In registers remain the current ray space, the closest distance and six scalars; the triangle test
@@ -107,29 +108,41 @@ __device__ __forceinline__ void pt_traverse_sched(const PtTlasView& tl, const Pt
             if (v == PT_NODE_SENTINEL) {
                 // nothing left above the instance: the ray is finished, its world-space form is not needed
                 if (stk.sp == 0) { v = PT_NODE_DONE; continue; }
-                // a few lanes at a time get here, so this must not wait for global memory or divide
-                pt_ray_space_init(cur, ws[0 * PT_TRAVERSE_BLOCK], ws[1 * PT_TRAVERSE_BLOCK], ws[2 * PT_TRAVERSE_BLOCK],
-                                  ws[3 * PT_TRAVERSE_BLOCK], ws[4 * PT_TRAVERSE_BLOCK], ws[5 * PT_TRAVERSE_BLOCK]);
+                // a few lanes at a time get here and the whole wave pays for what they do: no global memory,
+                // no division (reading the ray back later, with the lanes of its next phase, was measured
+                // slower: the test in every box step costs more than the batching saves)
+                cur.ox = ws[0 * PT_TRAVERSE_BLOCK]; cur.oy = ws[1 * PT_TRAVERSE_BLOCK]; cur.oz = ws[2 * PT_TRAVERSE_BLOCK];
+                cur.dx = ws[3 * PT_TRAVERSE_BLOCK]; cur.dy = ws[4 * PT_TRAVERSE_BLOCK]; cur.dz = ws[5 * PT_TRAVERSE_BLOCK];
+                cur.ix = ws[6 * PT_TRAVERSE_BLOCK]; cur.iy = ws[7 * PT_TRAVERSE_BLOCK]; cur.iz = ws[8 * PT_TRAVERSE_BLOCK];
+                cur.oox = cur.ox * cur.ix; cur.ooy = cur.oy * cur.iy; cur.ooz = cur.oz * cur.iz;
                 cur_inst = PT_NO_INSTANCE; tlo = tmin; thi = tmax;
                 v = stk.pop();
                 continue;
-            }
-            if (v == PT_NODE_DONE) {
-                const uint32_t qi = (uint32_t)PT_COLD(4);
-                PtHit out; out.instance = (uint32_t)PT_COLD(0); out.primitive = (uint32_t)PT_COLD(1); out.u = __int_as_float(PT_COLD(2)); out.v = __int_as_float(PT_COLD(3));
-                const uint32_t dst = BY_ID ? __float_as_uint(q1[qi].w) : qi;
-                if (BY_ID) hits[dst] = out;     // the caller's array: no alignment beyond the record's own
-                else pt_stream_store((float4*)&hits[dst], make_float4(__uint_as_float(out.instance), __uint_as_float(out.primitive), out.u, out.v));
-                if (BY_ID && t_out) t_out[dst] = best_t;
             }
             node = v;
             return;
         }
     };
 
+    // A finished ray keeps its closest hit in `cold` until its lane is refilled (or the wave ends): rays
+    // finish one or two lanes at a time, and a record written where the ray ends costs the whole wave
+    // a pass per ray (10 % of the kernel); written here, one pass serves every lane that waits.
+    PT_COLD(4) = -1;               // queue slot of the ray whose record is still to be written, or -1 (a flag in a register was measured 1 % slower)
+    auto flush = [&]() {
+        if (node == PT_NODE_DONE && PT_COLD(4) != -1) {
+            const uint32_t qi = (uint32_t)PT_COLD(4);
+            PtHit out; out.instance = (uint32_t)PT_COLD(0); out.primitive = (uint32_t)PT_COLD(1); out.u = __int_as_float(PT_COLD(2)); out.v = __int_as_float(PT_COLD(3));
+            const uint32_t dst = BY_ID ? __float_as_uint(q1[qi].w) : qi;
+            if (BY_ID) hits[dst] = out;     // the caller's array: no alignment beyond the record's own
+            else pt_stream_store((float4*)&hits[dst], make_float4(__uint_as_float(out.instance), __uint_as_float(out.primitive), out.u, out.v));
+            if (BY_ID && t_out) t_out[dst] = best_t;
+            PT_COLD(4) = -1;
+        }
+    };
     for (;;) {
         // ------------------------------------------------------------------ refill idle lanes
         unsigned long long idle = __ballot(node == PT_NODE_DONE);
+        if (idle == ~0ull || __popcll(idle) >= PT_SCHED_REFILL) flush();
         if (!drained && (idle == ~0ull || __popcll(idle) >= PT_SCHED_REFILL)) {
             while (idle) {
                 if (wcur == wend) {
@@ -164,6 +177,7 @@ __device__ __forceinline__ void pt_traverse_sched(const PtTlasView& tl, const Pt
                     pt_ray_space_init(cur, o.x, o.y, o.z, d.x, d.y, d.z);
                     ws[0 * PT_TRAVERSE_BLOCK] = cur.ox; ws[1 * PT_TRAVERSE_BLOCK] = cur.oy; ws[2 * PT_TRAVERSE_BLOCK] = cur.oz;
                     ws[3 * PT_TRAVERSE_BLOCK] = cur.dx; ws[4 * PT_TRAVERSE_BLOCK] = cur.dy; ws[5 * PT_TRAVERSE_BLOCK] = cur.dz;
+                    ws[6 * PT_TRAVERSE_BLOCK] = cur.ix; ws[7 * PT_TRAVERSE_BLOCK] = cur.iy; ws[8 * PT_TRAVERSE_BLOCK] = cur.iz;
                     cur_inst = PT_NO_INSTANCE; tlo = tmin; thi = tmax;
                     best_t = tmax;
                     stk.sp = 0;
@@ -180,7 +194,7 @@ __device__ __forceinline__ void pt_traverse_sched(const PtTlasView& tl, const Pt
         int n_leaf = __popcll(__ballot(want_leaf));
         const int n_enter = __popcll(__ballot(want_enter));
         if (n_node + n_leaf + n_enter == 0) {
-            if (drained) break;
+            if (drained) { flush(); break; }
             continue;
         }
         // ------------------------------------------------------------------ vote for one phase
