@@ -102,22 +102,17 @@ __device__ __forceinline__ void pt_traverse_sched(const PtTlasView& tl, const Pt
     cur.ox = cur.oy = cur.oz = cur.dx = cur.dy = cur.dz = cur.ix = cur.iy = cur.iz = cur.oox = cur.ooy = cur.ooz = 0.0f;
 
     // Takes the next item for this lane after the current one is exhausted: pops until an inner node,
-    // a leaf or the end of the ray comes up; leaving an instance restores the world-space ray.
+    // a leaf, the end of an instance's BLAS (with something left above it) or the end of the ray comes up.
     auto advance = [&](int v) {
         for (;;) {
             if (v == PT_NODE_SENTINEL) {
                 // nothing left above the instance: the ray is finished, its world-space form is not needed
                 if (stk.sp == 0) { v = PT_NODE_DONE; continue; }
-                // a few lanes at a time get here and the whole wave pays for what they do: no global memory,
-                // no division (reading the ray back later, with the lanes of its next phase, was measured
-                // slower: the test in every box step costs more than the batching saves)
-                cur.ox = ws[0 * PT_TRAVERSE_BLOCK]; cur.oy = ws[1 * PT_TRAVERSE_BLOCK]; cur.oz = ws[2 * PT_TRAVERSE_BLOCK];
-                cur.dx = ws[3 * PT_TRAVERSE_BLOCK]; cur.dy = ws[4 * PT_TRAVERSE_BLOCK]; cur.dz = ws[5 * PT_TRAVERSE_BLOCK];
-                cur.ix = ws[6 * PT_TRAVERSE_BLOCK]; cur.iy = ws[7 * PT_TRAVERSE_BLOCK]; cur.iz = ws[8 * PT_TRAVERSE_BLOCK];
-                cur.oox = cur.ox * cur.ix; cur.ooy = cur.oy * cur.iy; cur.ooz = cur.oz * cur.iz;
-                cur_inst = PT_NO_INSTANCE; tlo = tmin; thi = tmax;
-                v = stk.pop();
-                continue;
+                // a few lanes at a time get here and the whole wave pays for what they do: the lane waits
+                // for the instance phase, which takes it back to world space together with the lanes that
+                // enter or leave an instance then
+                node = v;
+                return;
             }
             node = v;
             return;
@@ -189,7 +184,7 @@ __device__ __forceinline__ void pt_traverse_sched(const PtTlasView& tl, const Pt
         }
         bool want_node = (unsigned)node < (unsigned)PT_NODE_DONE;
         bool want_leaf = node < 0 && cur_inst != PT_NO_INSTANCE;
-        const bool want_enter = node < 0 && cur_inst == PT_NO_INSTANCE;
+        const bool want_enter = (node < 0 && cur_inst == PT_NO_INSTANCE) || node == PT_NODE_SENTINEL;   // enters or leaves an instance
         int n_node = __popcll(__ballot(want_node));
         int n_leaf = __popcll(__ballot(want_leaf));
         const int n_enter = __popcll(__ballot(want_enter));
@@ -248,7 +243,15 @@ __device__ __forceinline__ void pt_traverse_sched(const PtTlasView& tl, const Pt
             } while (--steps > 0 && n_leaf >= PT_SCHED_LEAF_VOTES / 2);
         } else {
             PT_STAT(2, 1); PT_STAT(5, n_enter);
-            if (want_enter) {
+            if (node == PT_NODE_SENTINEL) {        // back to world space; something is left on the stack
+                cur.ox = ws[0 * PT_TRAVERSE_BLOCK]; cur.oy = ws[1 * PT_TRAVERSE_BLOCK]; cur.oz = ws[2 * PT_TRAVERSE_BLOCK];
+                cur.dx = ws[3 * PT_TRAVERSE_BLOCK]; cur.dy = ws[4 * PT_TRAVERSE_BLOCK]; cur.dz = ws[5 * PT_TRAVERSE_BLOCK];
+                cur.ix = ws[6 * PT_TRAVERSE_BLOCK]; cur.iy = ws[7 * PT_TRAVERSE_BLOCK]; cur.iz = ws[8 * PT_TRAVERSE_BLOCK];
+                cur.oox = cur.ox * cur.ix; cur.ooy = cur.oy * cur.iy; cur.ooz = cur.oz * cur.iz;
+                cur_inst = PT_NO_INSTANCE; tlo = tmin; thi = tmax;
+                node = stk.pop();
+            }
+            if (node < 0 && cur_inst == PT_NO_INSTANCE) {
                 // the whole record is requested at once: one round trip, not one per use
                 const float4* q = tl.inst[(~(uint32_t)node) >> 3].q;
                 const float4 r0 = q[0], r1 = q[1], r2 = q[2], blo = q[3], bhi = q[4], misc = q[5];
