@@ -231,10 +231,17 @@ __device__ __forceinline__ void pt_texture_rgb(const uint32_t* __restrict__ texe
     float fu = floorf(U), fv = floorf(V);
     float a = U - fu, bb = V - fv;
     long long i0 = (long long)fu, j0 = (long long)fv;
-    int x0 = (int)(i0 % W); if (x0 < 0) x0 += W;
-    int x1 = (int)((i0 + 1) % W); if (x1 < 0) x1 += W;
-    int y0 = (int)(j0 % H); if (y0 < 0) y0 += H;
-    int y1 = (int)((j0 + 1) % H); if (y1 < 0) y1 += H;
+    int x0, x1, y0, y1;
+    if (((W & (W - 1)) | (H & (H - 1))) == 0) {
+        // power-of-two sizes: the non-negative remainder is a mask (a 64-bit division costs a hundred instructions)
+        x0 = (int)(i0 & (W - 1)); x1 = (int)((i0 + 1) & (W - 1));
+        y0 = (int)(j0 & (H - 1)); y1 = (int)((j0 + 1) & (H - 1));
+    } else {
+        x0 = (int)(i0 % W); if (x0 < 0) x0 += W;
+        x1 = (int)((i0 + 1) % W); if (x1 < 0) x1 += W;
+        y0 = (int)(j0 % H); if (y0 < 0) y0 += H;
+        y1 = (int)((j0 + 1) % H); if (y1 < 0) y1 += H;
+    }
     uint32_t t00 = texels[(size_t)y0 * W + x0], t10 = texels[(size_t)y0 * W + x1];
     uint32_t t01 = texels[(size_t)y1 * W + x0], t11 = texels[(size_t)y1 * W + x1];
     float out[3];

@@ -113,6 +113,29 @@ def test_render_frame_bit_exact(name, w, h, spp, schedule, request, monkeypatch)
         r.close()
 
 
+@pytest.mark.parametrize("tw,th", [(37, 53), (64, 24), (1, 7)])
+def test_texture_sizes_that_are_not_powers_of_two(tw, th, cube):
+    """REPEAT addressing with the cube's uvs in [-1, 1] on textures whose sizes are not powers of two
+    (the sampler wraps those by remainder, powers of two by mask)."""
+    import copy
+    from pt_amd import camera
+    scene = copy.deepcopy(cube)
+    tex = [i for i, im in enumerate(scene.tables.images) if i > 0 and im.shape[0] > 2]
+    assert tex
+    rng = np.random.default_rng(tw * 100 + th)
+    for i in tex:
+        scene.tables.images[i] = rng.integers(0, 256, size=(th, tw, 4), dtype=np.uint8)
+    w, h, spp = 80, 60, 8
+    orc = _oracle(scene)
+    r = _renderer(scene, w, h)
+    try:
+        r.render(spp=spp, max_depth=10, frame=0)
+        want, _ = orc.render_frame(camera.camera_uniform(w, h), w, h, frame=0, spp=spp, threads=8)
+        assert _float_eq(r.last_result(), want)
+    finally:
+        r.close()
+
+
 HELMET_CAMERA = dict(eye=(0.15, 0.1, 0.75), center=(0.0, 0.0, 0.0), fov_deg=50.0)
 
 
