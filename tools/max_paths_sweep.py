@@ -1,3 +1,5 @@
+"""Throughput against the size of a step: samples per pixel per pt_trace call with the whole step in one pixel chunk
+(pt_ctx_set_max_paths), one and two frames in flight; dragon stand-in at 1920x1080 (run on the GPU box)."""
 import sys, time, os
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
@@ -8,7 +10,7 @@ scene = bench.build_scene("dragon")
 stream = torch.cuda.current_stream().cuda_stream
 r = hip.Renderer(scene, W, H, device=0, stream=stream)
 accum = torch.zeros(H * W * 4, dtype=torch.float32, device="cuda")
-for spp, mp, fif in [(256, 1 << 29, 1), (256, 1 << 29, 2), (192, 3 << 27, 3), (384, 3 << 28, 1)]:
+for spp, mp, fif in [(64, 1 << 27, 1), (128, 1 << 28, 1), (192, 3 << 27, 1), (256, 1 << 29, 1), (384, 3 << 28, 1), (128, 1 << 28, 2), (192, 3 << 27, 2), (256, 1 << 29, 2)]:
     r.ctx.set_frames_in_flight(fif)
     r.ctx.set_max_paths(mp)
     for f in range(max(2, fif)):
