@@ -106,8 +106,8 @@ def main():
     ap.add_argument("--spp", type=int, default=256,
                     help="samples per pixel per step (one pt_trace call). The whole step is resident at once (160 bytes of queues "
                          "and records per path: 85 GB per step in flight at 1080p x 256); throughput rises with the step because "
-                         "every bounce level is one launch whose ramp-down is a fixed cost: 64 spp 7.09, 128 spp 7.39, 256 spp "
-                         "7.53 Grays/s on the dragon frame. If the queues do not fit, the step is halved until they do")
+                         "every bounce level is one launch whose ramp-down is a fixed cost: +4 %% from 64 to 128 spp, +6 %% to 256 on the "
+                         "dragon frame. If the queues do not fit, the step is halved until they do")
     ap.add_argument("--max-paths", type=int, default=0,
                     help="paths per pixel chunk (library default 2^27); 0: the whole step in one chunk")
     ap.add_argument("--max-depth", type=int, default=10)
