@@ -185,6 +185,17 @@ int pt_scene_set_tables(PtContext* ctx,
 int pt_intersect(PtContext* ctx, const PtTlas* tlas, uint32_t n, const float* origins_dev, const float* dirs_dev,
                  float tmin, float tmax, PtHit* hits_dev, float* t_dev);
 
+/* pt_intersect for callers that cannot allocate device memory: code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc.  Has no counterpart in the reference.  Same
+ * arguments and results as pt_intersect; the ray queues, counters and stack slices come from a fixed
+ * array that every GPU the library runs on holds until the process ends (89 MiB), so n is limited to
+ * 1,048,576 rays (PT_ERROR_LIMIT above that) and the call neither allocates nor frees.  It runs on
+ * the context's stream.  Every call on one GPU shares that GPU's array: calls that overlap on one GPU
+ * (other streams, other contexts, other threads) race; calls on one stream follow each other. */
+#define PT_INTERSECT_NOALLOC_MAX_RAYS (1u << 20)
+int pt_intersect_noalloc(PtContext* ctx, const PtTlas* tlas, uint32_t n, const float* origins_dev, const float* dirs_dev,
+                         float tmin, float tmax, PtHit* hits_dev, float* t_dev);
+
 /* Replaces cmdTraceRaysKHR(width, height, 1) with the ray_gen / closest_hit / miss pipeline
  * (source/renderer.cpp:109-122): one frame of samples_per_frame paths per pixel, at most
  * max_depth rays per path, accumulated into accum_dev according to accum_mode.

@@ -114,6 +114,7 @@ int pt_ctx_create(int device_id, void* hip_stream, PtContext** out)
         pt_ctx_destroy(c);
         return PT_ERROR_HIP;
     }
+    if (int rc = pt_noalloc_setup(c)) { pt_ctx_destroy(c); return rc; }
     *out = c;
     return PT_OK;
 }

@@ -168,6 +168,9 @@ int pt_lane_begin(PtContext* ctx, PtLane** out);            // next lane, ordere
 int pt_lanes_join(PtContext* ctx);                          // the caller's stream waits for every lane (no host wait)
 int pt_lanes_sync(PtContext* ctx);                          // the host waits for every lane and the caller's stream
 
+// pt_trace.hip: looks up the device address of the fixed workspace of pt_intersect_noalloc (once per device)
+int pt_noalloc_setup(PtContext* ctx);
+
 // pt_build.hip
 int pt_build_wide(PtContext* ctx, const PtBvhNode* nodes_dev, uint32_t node_count, void** wide_out, uint32_t* count_out, uint32_t* depth_out);
 int pt_build_lbvh(PtContext* ctx, const float* prim_boxes_dev /* n x 6: lo, hi */, uint32_t n, uint32_t max_leaf,

@@ -732,6 +732,69 @@ PtTlasView view_of(const PtTlas* t)
 
 } // namespace
 
+// ---- pt_intersect for callers that cannot allocate --------------------------------------------
+// The two ray streams, the queue counters and the stack-overflow slices that pt_intersect takes from
+// hipMalloc live in one file-scope device array instead; each GPU the library runs on holds its own
+// copy until the process ends.  Sized for kNaMaxRays rays and a grid of kNaBlocks blocks:
+// rays 2 x 16 MiB, counters 1 MiB, stack slices 56 MiB.  Every call on a GPU uses that GPU's one
+// array, so calls that overlap on one GPU (two streams, two contexts, two threads) race.
+constexpr uint32_t kNaMaxRays = 1u << 20;
+constexpr int kNaBlocks = 512;
+constexpr size_t kNaStream = sizeof(float4) * (size_t)kNaMaxRays;                       // one ray stream: shard capacity x kShards slots
+constexpr size_t kNaCounters = (sizeof(uint32_t) * kCounterWords + 255) / 256 * 256;
+constexpr size_t kNaSpill = sizeof(int) * PT_SPILL_STACK * (size_t)kNaBlocks * kBlock;
+constexpr size_t kNaBytes = 2 * kNaStream + kNaCounters + kNaSpill;
+static __device__ __align__(256) unsigned char scratch[kNaBytes];
+
+constexpr int kNaMaxDevices = 64;
+static unsigned char* g_scratch_ptr[kNaMaxDevices];    // device address of `scratch` on each GPU (the array's name is only a host-side stand-in)
+static int g_na_blocks[kNaMaxDevices];
+
+// Called by pt_ctx_create with the context's device current: looks up this GPU's copy of the array
+// once and the grid of the traversal kernel, so that the entry point itself asks the runtime for nothing.
+int pt_noalloc_setup(PtContext* ctx)
+{
+    PT_REQUIRE(ctx->device >= 0 && ctx->device < kNaMaxDevices, "device index beyond the table of scratch addresses");
+    if (g_scratch_ptr[ctx->device]) return PT_OK;
+    unsigned char* ptr = nullptr;
+    PT_HIP_CHECK(hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch)));
+    PT_REQUIRE(ptr != nullptr, "hipGetSymbolAddress returned a null address");
+    g_na_blocks[ctx->device] = std::min(kNaBlocks, persistent_blocks(ctx, (const void*)k_intersect<true>));
+    g_scratch_ptr[ctx->device] = ptr;
+    return PT_OK;
+}
+
+extern "C" int pt_intersect_noalloc(PtContext* ctx, const PtTlas* tlas, uint32_t n, const float* origins_dev, const float* dirs_dev,
+                                    float tmin, float tmax, PtHit* hits_dev, float* t_dev)
+{
+    PT_REQUIRE(ctx && tlas && origins_dev && dirs_dev && hits_dev, "null argument");
+    PT_REQUIRE(tlas->ctx == ctx, "the TLAS belongs to another context");
+    if (n > kNaMaxRays) {
+        pt_set_error("pt_intersect_noalloc: %u rays exceed the fixed workspace of %u rays; split the call or use pt_intersect", n, kNaMaxRays);
+        return PT_ERROR_LIMIT;
+    }
+    if (n == 0) return PT_OK;
+    unsigned char* base = g_scratch_ptr[ctx->device];
+    PT_REQUIRE(base != nullptr, "the fixed workspace was not set up for this device");
+    PT_HIP_CHECK(hipSetDevice(ctx->device));
+    float4* q0 = (float4*)base;
+    float4* q1 = (float4*)(base + kNaStream);
+    uint32_t* counters = (uint32_t*)(base + 2 * kNaStream);
+    int* spill = (int*)(base + 2 * kNaStream + kNaCounters);
+    // per-shard capacity for n rays, as ensure_workspace sizes it: never more than kNaMaxRays / kShards
+    const uint64_t groups = ((uint64_t)n + kDealPaths - 1) / kDealPaths;
+    const uint32_t cap = (uint32_t)(((groups + kShards - 1) / kShards) * kDealPaths);
+    hipStream_t st = ctx->stream;
+    // the array keeps what the last call left: sizes and work counters start at zero
+    PT_HIP_CHECK(hipMemsetAsync(counters, 0, sizeof(uint32_t) * kCounterWords, st));
+    k_pack_rays<<<(n + kBlock - 1) / kBlock, kBlock, 0, st>>>(n, cap, origins_dev, dirs_dev, q0, q1, counters);
+    PtTlasView tv; tv.nodes = (const float4*)tlas->pool_nodes; tv.tris = tlas->pool_tris; tv.inst = tlas->inst;
+    const uint32_t thr = ctx->traversal_mode == 0 ? 0xFFFFFFFFu : (ctx->traversal_mode == 1 ? 0u : ctx->sched_min_rays);
+    k_intersect<true><<<g_na_blocks[ctx->device], kBlock, 0, st>>>(tv, counters, 0, cap, q0, q1, tmin, tmax, hits_dev, t_dev, spill, thr);
+    PT_HIP_CHECK(hipGetLastError());
+    return PT_OK;
+}
+
 extern "C" {
 
 int pt_intersect(PtContext* ctx, const PtTlas* tlas, uint32_t n, const float* origins_dev, const float* dirs_dev,

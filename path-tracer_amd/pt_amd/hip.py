@@ -51,6 +51,7 @@ SIGNATURES = {
     "pt_tlas_download": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "pt_scene_set_tables": (_i, [_vp, _vp, _u32, _vp, _u32, _vp, _u32, _vp, _u32]),
     "pt_intersect": (_i, [_vp, _vp, _u32, _vp, _vp, _f, _f, _vp, _vp]),
+    "pt_intersect_noalloc": (_i, [_vp, _vp, _u32, _vp, _vp, _f, _f, _vp, _vp]),
     "pt_trace": (_i, [_vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp]),
     "pt_trace_last_result": (_i, [_vp, _vp]),
     "pt_trace_stats": (_i, [_vp, _vp]),
