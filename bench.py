@@ -5,57 +5,92 @@
 
 One step = one pt_trace call of --spp samples per pixel over the whole 1920x1080 image of the
 dragon scene (procedural stand-in for the missing DragonAttenuation.bin), all inputs resident in
-HBM; --frames-in-flight steps may overlap on the library's internal streams (default here: 2, the
-library's own default is 3).
+HBM.  The library can keep several steps in flight on internal streams; how many is chosen by
+measurement during the warm-up unless --frames-in-flight says so.
 With N > 1 (one process per GPU under torch.distributed.run) rank r renders frames
 r, r+N, r+2N, ... (samples-per-pixel sharding) into its own float sum buffer and the buffers are
-summed with one RCCL all-reduce inside the timed region; per-GPU work is fixed, so scaling is weak.
-Rank 0 prints one JSON line.
+summed with one RCCL all-reduce inside the timed region.  By default every rank renders --steps
+steps (per-GPU work fixed: weak scaling); with --total-spp S the S samples per pixel of ONE image
+are split over the ranks (total work fixed: strong scaling, time to image).
+Rank 0 prints one JSON line.  After the timed region, at one GPU, the metric's second scene (the
+Cornell box) is timed for three steps and a bounded CPU sample of the workload is timed on the host.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
 import time
 
-import numpy as np
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "path-tracer_amd"))
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E peak
+CLOCK_GHZ = 2.4           # MI355X peak engine clock
+VALU_PEAK_PER_SIMD = 0.5  # wave64 vector instructions per cycle per SIMD: 157.3 TFLOP/s fp32 = 256 CUs x 4 SIMDs x 64 lanes x 2 flop x 2.4 GHz x 0.5
 
 
-def measured_traffic(workload_key):
-    """HBM-side bytes per intersect launch from the committed PMC passes (profiles/traffic.json,
-    written by tools/pmc_traffic.py from separate FETCH_SIZE / WRITE_SIZE runs of this workload);
-    None when no pass was recorded for the workload."""
+def source_hash():
+    """Identifies the kernel sources a PMC record was collected with."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "path-tracer_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_record(workload_key):
+    """Counters of the traversal launches of this workload from separate rocprofv3 --pmc passes
+    (profiles/traffic.json, written by tools/pmc_traffic.py): memory-side bytes and wave64 vector
+    instructions per launch.  None when no pass was recorded for the workload."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            rec = json.load(f).get(workload_key)
-        return float(rec["bytes_per_launch"]) if rec else None
-    except (OSError, ValueError, KeyError):
+            return json.load(f).get(workload_key)
+    except (OSError, ValueError):
         return None
 
 
-def valu_issue(workload_key, avg_launch_ms, n_simds):
-    """Vector-instruction issue rate of the traversal launches: wave64 vector instructions per launch
-    (SQ_INSTS_VALU of this workload, profiles/traffic.json) over the launches' average duration measured
-    in this run, per SIMD and 2.4 GHz cycle.  The ceilings are what one SIMD issues of a single
-    instruction kind with 2-8 waves (tools/micro/valu_rate.hip): 0.40 for the full-rate kind (fma, add, mul,
-    and/or/xor, mov), 0.235 for the half-rate kind (cndmask, min/max, compares, conversions), of which
-    a traversal step is two thirds.  With several frames in flight the launches share the GPU and
-    the rate per launch is lower by the stretch."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            rec = json.load(f).get(workload_key)
-        n = float(rec["valu_insts_per_launch"])
-    except (OSError, ValueError, KeyError, TypeError):
-        return None
-    if avg_launch_ms <= 0:
-        return None
-    return {"insts_per_cycle_per_simd": n / (avg_launch_ms * 1e-3 * n_simds * 2.4e9), "valu_insts_per_launch": n,
-            "simds": n_simds, "clock_ghz": 2.4, "ceiling_half_rate_kind": 0.235, "ceiling_full_rate_kind": 0.40}
+def make_roofline(launches, total_ms, rays, n_simds, pmc, compulsory_bytes, survey_bytes_per_ray, frames_in_flight, per_kernel):
+    """The roofline object of the bench line for the traversal launches (k_primary + k_intersect), whose
+    durations were measured with HIP events while each launch had the GPU to itself.
+
+    The kernels are bound by vector-instruction issue, so that is the headline: achieved = wave64 vector
+    instructions per launch (SQ_INSTS_VALU, PMC pass of the same workload and sources) / average launch
+    duration; peak = 0.5 instructions per cycle per SIMD (what the 157.3 TFLOP/s fp32 figure implies)
+    x SIMDs x 2.4 GHz.  Beside it `hbm`: measured memory-side bytes per launch / duration against 8 TB/s,
+    and the bytes a launch cannot avoid (rays read, hit records and path state written).  `survey_model`
+    keeps the modelled bytes per ray of a binary BVH in full precision (32 B per box test, 36 B per
+    triangle test), which the quantised wide tree held in L2 does not move: it is not a bound."""
+    avg_ms = total_ms / max(launches, 1)
+    sec = avg_ms * 1e-3
+    peak = VALU_PEAK_PER_SIMD * n_simds * CLOCK_GHZ      # G wave-instructions per second
+    insts = float(pmc["valu_insts_per_launch"]) if pmc and pmc.get("valu_insts_per_launch") else None
+    traffic = float(pmc["bytes_per_launch"]) if pmc and pmc.get("bytes_per_launch") else None
+    achieved = insts / sec / 1e9 if insts and sec > 0 else None
+    out = {
+        "bound": "valu", "kernel": "k_intersect + k_primary", "achieved": achieved, "peak": peak, "unit": "G wave64 vector instructions/s",
+        "frac": achieved / peak if achieved is not None else None, "traffic": traffic,
+        "launches": launches, "avg_launch_ms": avg_ms, "rays_per_launch": rays / max(launches, 1), "frames_in_flight": frames_in_flight,
+        "valu_insts_per_launch": insts, "valu_insts_per_ray": insts * launches / rays if insts and rays else None,
+        "insts_per_cycle_per_simd": achieved / (n_simds * CLOCK_GHZ) if achieved is not None else None,
+        "simds": n_simds, "clock_ghz": CLOCK_GHZ,
+        "intersect_rays_per_s": rays / (total_ms * 1e-3) if total_ms > 0 else 0.0,
+        "per_kernel": per_kernel,
+        "pmc_source": None if not pmc else {"file": "profiles/traffic.json", "command": pmc.get("command"), "source_hash": pmc.get("source_hash"),
+                                            "stale": pmc.get("source_hash") not in (None, source_hash())},
+    }
+    hbm_ach = traffic / sec / 1e9 if traffic and sec > 0 else None
+    comp = compulsory_bytes / max(launches, 1)
+    out["hbm"] = {"achieved": hbm_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_ach / HBM_PEAK_GBS if hbm_ach is not None else None,
+                  "traffic": traffic, "compulsory_bytes_per_launch": comp,
+                  "traffic_over_compulsory": traffic / comp if traffic and comp > 0 else None}
+    if survey_bytes_per_ray:
+        out["survey_model"] = {"bytes_per_ray": survey_bytes_per_ray,
+                               "modelled_gbs": rays * survey_bytes_per_ray / (total_ms * 1e-3) / 1e9 if total_ms > 0 else 0.0,
+                               "note": "box and triangle tests of the CPU port's binary BVH x 32 B / 36 B + 48 B per ray; a model, not traffic and not a bound"}
+    return out
 
 
 def build_scene(name):
@@ -63,35 +98,58 @@ def build_scene(name):
     from pt_amd.scene import Scene
     if name == "dragon":
         return procedural.dragon_standin()
-    return Scene.load_npz(os.path.join(ROOT, "tests", "golden", f"scene_{name}.npz"))
+    if name == "composite":
+        g = os.path.join(ROOT, "tests", "golden")
+        return procedural.composite(Scene.load_npz(os.path.join(g, "scene_cornell.npz")),
+                                    procedural.with_native_texture_sizes(Scene.load_npz(os.path.join(g, "scene_helmet.npz"))))
+    scene = Scene.load_npz(os.path.join(ROOT, "tests", "golden", f"scene_{name}.npz"))
+    if name == "helmet":
+        scene = procedural.with_native_texture_sizes(scene)
+    return scene
 
 
-def cpu_baseline(scene, width, height, spp, max_depth):
+def scene_camera(name, W, H):
+    from pt_amd import camera
+    if name == "helmet":       # the reference's camera frames the 0.3-unit helmet tiny
+        return camera.camera_uniform(W, H, eye=(0.15, 0.1, 0.75), center=(0.0, 0.0, 0.0), fov_deg=50.0)
+    return camera.camera_uniform(W, H)
+
+
+def host_threads():
+    """Threads of the CPU baseline: the CPU share of this job (the harness exports it as OMP_NUM_THREADS;
+    os.cpu_count() shows the whole machine, which a job sharing the host with others must not take)."""
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    share = os.environ.get("OMP_NUM_THREADS")
+    return max(1, min(avail, int(share))) if share and share.isdigit() else max(1, avail)
+
+
+def cpu_baseline(scene, cam, width, height, spp, max_depth):
     """Times the CPU oracle (a literal transcription of the shaders traversing its own BVH) on a
     bounded sample of the same workload: the full image at a reduced sample count."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O
-    from pt_amd import camera
-    threads = max(1, min(16, int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))))
+    threads = host_threads()
     orc = O.OracleScene(scene)
-    cam = camera.camera_uniform(width, height)
     t0 = time.perf_counter()
     _, st = orc.render_frame(cam, width, height, frame=0, spp=spp, max_depth=max_depth, threads=threads)
     dt = time.perf_counter() - t0
     rays = int(st["rays"])
     return {
         "value": rays / dt, "unit": "rays/s", "cores": threads, "kind": "port",
-        "sample": f"{width}x{height}, {spp} spp, depth {max_depth}: {rays} rays in {dt:.2f} s (trace phase only)",
-        "paths_per_s": int(st["paths"]) / dt,
+        "sample": f"{width}x{height}, {spp} spp, depth {max_depth}: {rays} rays in {dt:.2f} s (trace phase only) on {threads} threads, "
+                  f"the job's CPU share of a host with {os.cpu_count()} logical CPUs",
+        "host_logical_cpus": os.cpu_count(), "paths_per_s": int(st["paths"]) / dt,
         "box_tests_per_ray": int(st["box_tests"]) / rays, "tri_tests_per_ray": int(st["tri_tests"]) / rays,
         "hit_fraction": int(st["hits"]) / rays, "textured_hit_fraction": int(st["tex_hits"]) / rays,
     }
 
 
-def run_steps(renderer, accum_ptr, n_steps, first_frame, rank, world, spp, max_depth):
-    """Rank `rank` renders its share of the frames [first_frame, first_frame + n_steps * world)."""
-    from pt_amd import hip, sharding
-    for f in sharding.frames_for_rank(rank, world, n_steps * world, first_frame):
+def run_frames(renderer, accum_ptr, frames, spp, max_depth):
+    from pt_amd import hip
+    for f in frames:
         renderer.render(spp=spp, max_depth=max_depth, accum_mode=hip.ACCUM_SUM_F32, accum_dev=accum_ptr, frame=f)
 
 
@@ -100,31 +158,31 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--scene", default="dragon", choices=["dragon", "cornell", "cube"])
+    ap.add_argument("--scene", default="dragon", choices=["dragon", "cornell", "cube", "helmet", "composite"])
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=256,
                     help="samples per pixel per step (one pt_trace call). The whole step is resident at once (160 bytes of queues "
-                         "and records per path: 85 GB per step in flight at 1080p x 256); throughput rises with the step because "
-                         "every bounce level is one launch whose ramp-down is a fixed cost: +4 %% from 64 to 128 spp, +6 %% to 256 on the "
-                         "dragon frame. If the queues do not fit, the step is halved until they do")
+                         "and records per path); every bounce level is one launch whose ramp-down is a fixed cost, so throughput rises "
+                         "with the step. If the queues do not fit, the step is halved until they do")
+    ap.add_argument("--total-spp", type=int, default=0,
+                    help="strong scaling: render ONE image of this many samples per pixel, its steps of --spp samples split over the ranks "
+                         "(--steps is then derived: total-spp / spp / ranks, rounded up)")
     ap.add_argument("--max-paths", type=int, default=0,
-                    help="paths per pixel chunk (library default 2^27); 0: the whole step in one chunk")
+                    help="paths per pixel chunk (library default 2^27); 0: the whole step in one chunk (at most 2^31 - 1 paths)")
     ap.add_argument("--max-depth", type=int, default=10)
-    ap.add_argument("--frames-in-flight", type=int, default=2,
-                    help="steps the library keeps in flight on separate streams (library default 3). With two, the shading and "
-                         "bounce-0 kernels of one step overlap the traversal of the other: +5.6 %% at 64 spp per step. Launches "
-                         "that share the GPU last longer than they would alone: --frames-in-flight 1 (or --serial-roofline) gives "
-                         "the kernels' exclusive durations")
-    ap.add_argument("--serial-roofline", action="store_true", help="accepted for older command lines; on by default at one GPU")
+    ap.add_argument("--frames-in-flight", type=int, default=0,
+                    help="steps the library keeps in flight on separate streams; 0 (default): one or two, whichever two timed "
+                         "warm-up steps show to be faster on this machine (two must win by 2 %% to pay for the second set of queues)")
+    ap.add_argument("--serial-roofline", action="store_true", help="accepted for older command lines")
     ap.add_argument("--no-serial-roofline", action="store_true",
-                    help="skip the three steps with one frame in flight that follow the timed region at one GPU (their kernel durations, "
-                         "each launch alone on the GPU, are reported as roofline.one_frame_at_a_time and are not part of `value`); "
-                         "for profiled runs, whose kernel statistics should hold the timed command's launches only")
+                    help="with several frames in flight: skip the three steps with one frame in flight that follow the timed region at one GPU "
+                         "(their launch durations, each launch alone on the GPU, are what `roofline` is computed from; without them it is "
+                         "computed from the timed region's overlapping launches and says so)")
     ap.add_argument("--cpu-spp", type=int, default=16, help="samples per pixel of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--secondary", action="store_true", help="also measure the cornell scene (extra launches: keep it out of profiled runs)")
-    ap.add_argument("--no-secondary", action="store_true", help="accepted for older command lines; the side measurement is off by default")
+    ap.add_argument("--secondary", action="store_true", help="accepted for older command lines; the Cornell measurement is on by default")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the Cornell steps after the timed region (profiled runs)")
     args = ap.parse_args()
 
     import torch
@@ -141,7 +199,9 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
+    backend = None
     if world > 1:
+        backend = "gloo" if rehearsal else "nccl"
         if rehearsal:
             dist.init_process_group("gloo")
         else:
@@ -149,20 +209,35 @@ def main():
 
     W, H = args.width, args.height
     scene = build_scene(args.scene)
-    stream = torch.cuda.current_stream().cuda_stream
+    cam = scene_camera(args.scene, W, H)
+    # a stream of our own, made torch's current one: the library enqueues on it (its handle is not the null
+    # stream's 0, which pt_ctx_create would take as "create one"), so torch's work and the library's are ordered
+    side = torch.cuda.Stream()
+    torch.cuda.set_stream(side)
+    stream = side.cuda_stream
+    assert stream != 0
     t0 = time.perf_counter()
-    r = hip.Renderer(scene, W, H, device=local_rank, stream=stream)
+    r = hip.Renderer(scene, W, H, device=local_rank, stream=stream, camera=cam)
     torch.cuda.synchronize()
     setup_s = time.perf_counter() - t0
     build_ms = sum(float(b.info()["build_ms"]) for b in r.blases) + float(r.tlas.info()["build_ms"])
     accum = torch.zeros(H * W * 4, dtype=torch.float32, device="cuda")
-    r.ctx.set_frames_in_flight(args.frames_in_flight)
+    torch.cuda.synchronize()
+
+    def set_chunk():
+        r.ctx.set_max_paths(args.max_paths if args.max_paths > 0 else min(W * H * args.spp, (1 << 31) - 64))
+
+    def my_frames(n_steps_per_rank, first):
+        return sharding.frames_for_rank(rank, world, n_steps_per_rank * world, first)
+
     # the first steps allocate the queues of every frame in flight: a step that does not fit the
     # device's memory is halved (same work per ray, more launches per sample)
+    fif = args.frames_in_flight if args.frames_in_flight > 0 else 1
+    r.ctx.set_frames_in_flight(fif)
     while True:
-        r.ctx.set_max_paths(args.max_paths if args.max_paths > 0 else min(W * H * args.spp, (1 << 31) - 64))
+        set_chunk()
         try:
-            run_steps(r, accum.data_ptr(), args.frames_in_flight, 2_000_000, rank, world, args.spp, args.max_depth)
+            run_frames(r, accum.data_ptr(), my_frames(fif, 2_000_000), args.spp, args.max_depth)
             r.ctx.sync()
             break
         except hip.PtError as e:
@@ -170,12 +245,45 @@ def main():
                 raise
             print(f"bench.py: {args.spp} spp per step does not fit ({e}); halving the step", file=sys.stderr)
             args.spp //= 2
+    fif_choice = None
+    if args.frames_in_flight == 0:
+        # one or two steps in flight, by measurement: two cost a second set of queues and must earn it
+        def timed(n_fif):
+            r.ctx.set_frames_in_flight(n_fif)
+            run_frames(r, accum.data_ptr(), my_frames(n_fif, 2_100_000), args.spp, args.max_depth)   # allocates this setting's queues
+            r.ctx.sync()
+            t = time.perf_counter()
+            run_frames(r, accum.data_ptr(), my_frames(2, 2_200_000), args.spp, args.max_depth)
+            r.ctx.sync()
+            return (time.perf_counter() - t) / 2
+        t1 = timed(1)
+        try:
+            t2 = timed(2)
+        except hip.PtError as e:
+            if "memory" not in str(e).lower():
+                raise
+            t2 = float("inf")
+        fif = 2 if t2 < 0.98 * t1 else 1
+        fif_choice = {"ms_per_step_1": 1e3 * t1, "ms_per_step_2": None if t2 == float("inf") else 1e3 * t2, "chosen": fif}
+        if world > 1:       # every rank runs the same setting
+            tf = torch.tensor([fif], dtype=torch.int64, device="cuda")
+            dist.all_reduce(tf, op=dist.ReduceOp.MIN)
+            fif = int(tf[0])
+        r.ctx.set_frames_in_flight(fif)
     if world > 1:
         # every rank runs the same step
         t_spp = torch.tensor([args.spp], dtype=torch.int64, device="cuda")
         dist.all_reduce(t_spp, op=dist.ReduceOp.MIN)
         args.spp = int(t_spp[0])
-        r.ctx.set_max_paths(args.max_paths if args.max_paths > 0 else min(W * H * args.spp, (1 << 31) - 64))
+        set_chunk()
+    strong = args.total_spp > 0
+    if strong:
+        total_steps = max(1, -(-args.total_spp // args.spp))
+        my_timed = sharding.frames_for_rank(rank, world, total_steps, 0)     # ranks may differ by one step
+        args.steps = -(-total_steps // world)
+    else:
+        total_steps = args.steps * world
+        my_timed = my_frames(args.steps, 0)
 
     def barrier():
         torch.cuda.synchronize()
@@ -185,24 +293,29 @@ def main():
 
     # warmup (frames that are not part of the timed set); at least one step per frame in flight, so
     # that every internal stream has allocated its path queues before the clock starts
-    run_steps(r, accum.data_ptr(), max(args.warmup, args.frames_in_flight), 1_000_000, rank, world, args.spp, args.max_depth)
+    run_frames(r, accum.data_ptr(), my_frames(max(args.warmup, fif), 1_000_000), args.spp, args.max_depth)
     r.ctx.sync()                    # frames in flight still add to the image
     sharding.allreduce_sum(accum)   # the collective's first call sets up its communicator and buffers: not timed
     accum.zero_()
     r.reset_stats()
-    # the dominant kernel (intersect) is bracketed by HIP events on the streams it runs on, during the timed steps
+    # the traversal launches are bracketed by HIP events on the streams they run on, during the timed steps
     r.set_profiling(True)
     r.profile()
     barrier()
     t0 = time.perf_counter()
-    run_steps(r, accum.data_ptr(), args.steps, 0, rank, world, args.spp, args.max_depth)
-    r.ctx.sync()                    # the all-reduce (torch's stream) follows every frame in flight
+    run_frames(r, accum.data_ptr(), my_timed, args.spp, args.max_depth)
+    r.fence()                       # the context's stream (torch's current one) waits for every frame in flight
+    ar0, ar1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ar0.record()
     sharding.allreduce_sum(accum)
+    ar1.record()
     barrier()
     elapsed = time.perf_counter() - t0
+    allreduce_ms = ar0.elapsed_time(ar1) if world > 1 else 0.0
     prof = r.profile()
     st = r.stats()
     rays_local, paths_local = int(st["rays"]), int(st["paths"])
+    rays_per_depth = [int(x) for x in st["rays_per_depth"][:args.max_depth]]
     t = torch.tensor([elapsed, float(rays_local), float(paths_local)], dtype=torch.float64, device="cuda")
     if world > 1:
         tmax = t.clone()
@@ -212,100 +325,82 @@ def main():
         rays, paths = float(t[1]), float(t[2])
     else:
         rays, paths = float(rays_local), float(paths_local)
-    # sanity: the reduced buffer holds every frame of every rank
+    # the reduced buffer holds every frame of every rank
     frames_seen = float(accum.view(-1, 4)[0, 3])
-    # the same kernel with one frame at a time, so that a launch has the GPU to itself (not part of `value`)
-    prof_serial = None
-    if rank == 0 and world == 1 and args.frames_in_flight > 1 and not args.no_serial_roofline:
+    if frames_seen != float(total_steps):
+        raise SystemExit(f"bench.py: the reduced image holds {frames_seen} frames, {total_steps} were rendered by {world} rank(s)")
+    # the same kernels with one frame at a time, so that a launch has the GPU to itself (not part of `value`)
+    prof_roof, roof_fif = prof, fif
+    if rank == 0 and world == 1 and fif > 1 and not args.no_serial_roofline:
         r.ctx.set_frames_in_flight(1)
-        run_steps(r, accum.data_ptr(), 1, 3_000_000, 0, 1, args.spp, args.max_depth)
+        run_frames(r, accum.data_ptr(), [3_000_000], args.spp, args.max_depth)
         r.profile()
-        run_steps(r, accum.data_ptr(), 2, 3_000_001, 0, 1, args.spp, args.max_depth)
-        prof_serial = r.profile()
+        run_frames(r, accum.data_ptr(), [3_000_001, 3_000_002], args.spp, args.max_depth)
+        prof_roof, roof_fif = r.profile(), 1
     r.set_profiling(False)
 
     if rank == 0:
         out = {
             "metric": "rays/s", "value": rays / elapsed, "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.scene} {W}x{H}, {args.spp} spp per step, max depth {args.max_depth}"
                                    + (" (procedural stand-in for the missing DragonAttenuation.bin: 134,995 triangles, 2 instances)" if args.scene == "dragon" else ""),
-                       "parallelism": f"spp-sharded x{world}, one RCCL all-reduce of the float sum buffer" if world > 1 else "single GPU",
-                       "triangles": scene.triangle_count(), "instances": len(scene.instances())},
-            "paths_per_s": paths / elapsed, "rays_per_path": rays / paths,
+                       "parallelism": {"scheme": f"spp-sharded x{world}, one sum all-reduce of the float image" if world > 1 else "single GPU",
+                                       "backend": backend, "world_size": world, "allreduce_ms": allreduce_ms,
+                                       "allreduce_bytes": accum.numel() * 4 if world > 1 else 0,
+                                       "steps_total": total_steps, "total_spp": total_steps * args.spp},
+                       "frames_in_flight": fif, "triangles": scene.triangle_count(), "instances": len(scene.instances())},
+            "paths_per_s": paths / elapsed, "rays_per_path": rays / paths, "time_to_image_s": elapsed,
             "frames_accumulated": frames_seen, "bvh_build_ms": build_ms, "setup_s": setup_s,
         }
+        if fif_choice:
+            out["config"]["frames_in_flight_choice"] = fif_choice
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(scene, W, H, args.cpu_spp, args.max_depth)
-            out["cpu_baseline"] = {k: cpu[k] for k in ("value", "unit", "cores", "kind", "sample")}
-            out["cpu_baseline"]["paths_per_s"] = cpu["paths_per_s"]
-        # algorithmic bytes of one intersect launch = rays x (32 B per box test + 36 B per triangle
-        # test + 32 B ray read + 16 B hit record written); box/triangle tests per ray are the CPU
-        # oracle's counts on its canonical BVH (fallback: the figures measured for this scene).
-        vn = cpu["box_tests_per_ray"] if cpu else 52.0
-        vt = cpu["tri_tests_per_ray"] if cpu else 2.7
-        hitf = cpu["hit_fraction"] if cpu else 0.46
-        texf = cpu["textured_hit_fraction"] if cpu else 0.29
-        bytes_intersect = 32.0 * vn + 36.0 * vt + 48.0
-        bytes_pipeline = 32.0 * vn + 36.0 * vt + hitf * 336.0 + texf * 16.0 + 176.0
-        # the traversal launches of a step: k_primary (bounce 0; its interval also holds the bounce's
-        # shading, which makes the figure conservative) and k_intersect (one per later bounce)
-        i_ms = float(prof["intersect_ms"]) + float(prof["primary_ms"])
-        i_rays = float(prof["intersect_rays"]) + float(prof["primary_rays"])
-        i_n = int(prof["intersect_launches"]) + int(prof["primary_launches"])
-        achieved = (i_rays * bytes_intersect) / (i_ms * 1e-3) / 1e9 if i_ms > 0 else 0.0
-        out["roofline"] = {
-            "bound": "hbm", "kernel": "k_intersect + k_primary", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS,
-            "traffic": measured_traffic(f"{args.scene} {W}x{H} {args.spp}spp depth{args.max_depth}"),
-            "launches": i_n, "avg_launch_ms": i_ms / max(i_n, 1), "rays_per_launch": i_rays / max(i_n, 1),
-            "frames_in_flight": args.frames_in_flight,
-            "bytes_per_ray": bytes_intersect, "box_tests_per_ray": vn, "tri_tests_per_ray": vt,
-            "intersect_rays_per_s": i_rays / (i_ms * 1e-3) if i_ms > 0 else 0.0,
-            "per_kernel": {
-                "k_primary": {"launches": int(prof["primary_launches"]),
-                              "avg_launch_ms": float(prof["primary_ms"]) / max(int(prof["primary_launches"]), 1),
-                              "rays_per_launch": float(prof["primary_rays"]) / max(int(prof["primary_launches"]), 1)},
-                "k_intersect": {"launches": int(prof["intersect_launches"]),
-                                "avg_launch_ms": float(prof["intersect_ms"]) / max(int(prof["intersect_launches"]), 1),
-                                "rays_per_launch": float(prof["intersect_rays"]) / max(int(prof["intersect_launches"]), 1)}},
-            "pipeline_bytes_per_ray": bytes_pipeline,
-            "pipeline_frac": (rays / elapsed / world) * bytes_pipeline / 1e9 / HBM_PEAK_GBS,
-        }
+            cpu = cpu_baseline(scene, cam, W, H, args.cpu_spp, args.max_depth)
+            out["cpu_baseline"] = {k: cpu[k] for k in ("value", "unit", "cores", "kind", "sample", "host_logical_cpus", "paths_per_s")}
+        p = prof_roof
+        i_ms = float(p["intersect_ms"]) + float(p["primary_ms"])
+        i_rays = float(p["intersect_rays"]) + float(p["primary_rays"])
+        i_n = int(p["intersect_launches"]) + int(p["primary_launches"])
+        per_kernel = {
+            "k_primary": {"launches": int(p["primary_launches"]), "avg_launch_ms": float(p["primary_ms"]) / max(int(p["primary_launches"]), 1),
+                          "rays_per_launch": float(p["primary_rays"]) / max(int(p["primary_launches"]), 1)},
+            "k_intersect": {"launches": int(p["intersect_launches"]), "avg_launch_ms": float(p["intersect_ms"]) / max(int(p["intersect_launches"]), 1),
+                            "rays_per_launch": float(p["intersect_rays"]) / max(int(p["intersect_launches"]), 1)}}
+        # bytes a traversal launch cannot avoid: k_intersect reads a 32-byte ray and writes a 16-byte hit record per
+        # ray; k_primary writes 64 bytes of path state per surviving path and a 16-byte result per path that ends
+        frames_roof = max(int(p["primary_launches"]), 1)
+        per_frame = [x / max(len(my_timed), 1) for x in rays_per_depth]
+        survivors = per_frame[1] if len(per_frame) > 1 else 0.0
+        compulsory = frames_roof * (48.0 * sum(per_frame[1:]) + 64.0 * survivors + 16.0 * (per_frame[0] - survivors))
+        survey = (32.0 * cpu["box_tests_per_ray"] + 36.0 * cpu["tri_tests_per_ray"] + 48.0) if cpu else None
         wkey = f"{args.scene} {W}x{H} {args.spp}spp depth{args.max_depth}"
         n_simds = 4 * torch.cuda.get_device_properties(local_rank).multi_processor_count
-        vi = valu_issue(wkey, i_ms / max(i_n, 1), n_simds)
-        if vi is not None:
-            out["roofline"]["valu_issue"] = vi
-        if prof_serial is not None and float(prof_serial["intersect_ms"]) > 0:
-            s_ms = float(prof_serial["intersect_ms"]) + float(prof_serial["primary_ms"])
-            s_rays = float(prof_serial["intersect_rays"]) + float(prof_serial["primary_rays"])
-            s_n = int(prof_serial["intersect_launches"]) + int(prof_serial["primary_launches"])
-            s_ach = (s_rays * bytes_intersect) / (s_ms * 1e-3) / 1e9
-            # launches of frames in flight share the GPU, which stretches each of them; this is the
-            # same measurement with frames strictly one after the other
-            out["roofline"]["one_frame_at_a_time"] = {"achieved": s_ach, "frac": s_ach / HBM_PEAK_GBS, "launches": s_n,
-                                                      "avg_launch_ms": s_ms / max(s_n, 1), "intersect_rays_per_s": s_rays / (s_ms * 1e-3)}
-            vs = valu_issue(wkey, s_ms / max(s_n, 1), n_simds)
-            if vs is not None:
-                out["roofline"]["one_frame_at_a_time"]["valu_issue"] = vs
-        if world == 1 and args.secondary and not args.no_secondary and args.scene == "dragon":
+        out["roofline"] = make_roofline(i_n, i_ms, i_rays, n_simds, pmc_record(wkey), compulsory, survey, roof_fif, per_kernel)
+        out["roofline"]["durations_from"] = ("the timed region" if prof_roof is prof else "three steps after the timed region") + \
+                                            f", {roof_fif} frame(s) in flight" + ("" if roof_fif == 1 else ": launches overlap, durations are stretched")
+        if world == 1 and not args.no_secondary and args.scene == "dragon":
+            # the metric's other scene, after the timed region
             r.close()
             c = hip.Renderer(build_scene("cornell"), W, H, device=local_rank, stream=stream)
+            c.ctx.set_frames_in_flight(fif)
+            c.ctx.set_max_paths(args.max_paths if args.max_paths > 0 else min(W * H * args.spp, (1 << 31) - 64))
             acc2 = torch.zeros(H * W * 4, dtype=torch.float32, device="cuda")
-            run_steps(c, acc2.data_ptr(), 3, 1_000_000, 0, 1, args.spp, args.max_depth)
+            run_frames(c, acc2.data_ptr(), range(1_000_000, 1_000_000 + max(2, fif)), args.spp, args.max_depth)
+            c.ctx.sync()
             c.reset_stats()
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            run_steps(c, acc2.data_ptr(), 3, 0, 0, 1, args.spp, args.max_depth)
+            run_frames(c, acc2.data_ptr(), range(3), args.spp, args.max_depth)
+            c.ctx.sync()
             torch.cuda.synchronize()
             dt = time.perf_counter() - t1
             s2 = c.stats()
-            out["cornell"] = {"rays_per_s": int(s2["rays"]) / dt, "paths_per_s": int(s2["paths"]) / dt,
-                              "workload": f"cornell {W}x{H}, {args.spp} spp per step, 3 steps"}
+            out["cornell"] = {"rays_per_s": int(s2["rays"]) / dt, "paths_per_s": int(s2["paths"]) / dt, "ms_per_step": 1e3 * dt / 3, "steps": 3,
+                              "workload": f"cornell {W}x{H}, {args.spp} spp per step, max depth {args.max_depth}, after the timed region"}
             c.close()
         print(json.dumps(out))
     if world > 1:

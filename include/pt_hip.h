@@ -101,8 +101,13 @@ enum { PT_ACCUM_SUM_F32 = 0,      /* float4 per pixel: rgb += frame result, a +=
 const char* pt_last_error(void);
 
 /* Replaces VulkanContext device/queue selection (source/vulkan_context.cpp:99-113): binds a GPU
- * and creates a stream.  hip_stream may be NULL (a new stream is created) or an existing
- * hipStream_t to enqueue on (for example PyTorch's current stream). */
+ * and a stream.  hip_stream = NULL: the library creates a non-blocking stream of its own, which is
+ * NOT ordered with the null stream or any stream of the caller (use pt_sync / pt_trace_fence and
+ * your own synchronisation around shared buffers).  Otherwise hip_stream is the hipStream_t to
+ * enqueue on, and everything this header says about "the context's stream" holds for it.  The null
+ * (legacy default) stream has the handle 0 and therefore cannot be passed as such: pass
+ * hipStreamLegacy or hipStreamPerThread for it, or a stream of your own (a framework's current
+ * stream may be the null stream: PyTorch's is unless a torch.cuda.Stream has been made current). */
 int pt_ctx_create(int device_id, void* hip_stream, PtContext** out);
 int pt_ctx_destroy(PtContext* ctx);
 /* Waits on the host for everything the context has enqueued, frames in flight included. */
@@ -227,9 +232,9 @@ typedef struct PtTraceProfile {
 int pt_ctx_set_profiling(PtContext* ctx, int enabled);
 int pt_trace_profile(PtContext* ctx, PtTraceProfile* out);
 
-/* Upper bound on paths resident at once per frame in flight (default 1<<27, about 21 GB of queues
- * when reached; queues are sized by the largest chunk actually traced); a larger frame is
- * rendered in pixel chunks. */
+/* Upper bound on paths resident at once per frame in flight, in [64, 2^31) (default 1<<27, about
+ * 21 GB of queues when reached; queues are sized by the largest chunk actually traced); a larger
+ * frame is rendered in pixel chunks. */
 int pt_ctx_set_max_paths(PtContext* ctx, uint64_t max_paths);
 
 /* Replaces the render-target -> swapchain blit (source/renderer.cpp:124-133): float sum buffer

@@ -889,6 +889,34 @@ int pt_build_lbvh(PtContext* ctx, const float* boxes, uint32_t n, uint32_t max_l
     return PT_OK;
 }
 
+// One cleanup path for the build entry points: the timing events, and the structure under
+// construction unless the build reaches its end and releases it.
+struct EventPair {
+    hipEvent_t a = nullptr, b = nullptr;
+    hipError_t create() { hipError_t e = hipEventCreate(&a); return e != hipSuccess ? e : hipEventCreate(&b); }
+    ~EventPair() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+};
+static void blas_free(PtBlas* b)
+{
+    (void)hipFree(b->nodes); (void)hipFree(b->tris); (void)hipFree(b->leaf_prims); (void)hipFree(b->sorted_keys); (void)hipFree(b->wide);
+    (void)hipFree(b->trav_nodes); (void)hipFree(b->trav_order);
+    delete b;
+}
+static void tlas_free(PtTlas* t)      // nothing in flight may still traverse the pool
+{
+    (void)hipFree(t->nodes); (void)hipFree(t->leaf_inst); (void)hipFree(t->inst); (void)hipFree(t->shade_inst);
+    for (auto& r : t->tri_records) (void)hipFree(r.dev);
+    (void)hipFree(t->pool_nodes); (void)hipFree(t->pool_tris);
+    delete t;
+}
+template <typename T, void (*FREE)(T*)>
+struct Owner {
+    T* p;
+    explicit Owner(T* q) : p(q) {}
+    ~Owner() { if (p) FREE(p); }
+    T* release() { T* q = p; p = nullptr; return q; }
+};
+
 // =============================================================================================
 extern "C" {
 
@@ -903,8 +931,9 @@ int pt_blas_build(PtContext* ctx, const void* vertices_dev, uint32_t vertex_stri
     PT_REQUIRE(max_leaf <= 8, "max_leaf must be at most 8");
     PT_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    hipEvent_t ev0, ev1;
-    PT_HIP_CHECK(hipEventCreate(&ev0)); PT_HIP_CHECK(hipEventCreate(&ev1));
+    EventPair ev;
+    PT_HIP_CHECK(ev.create());
+    const hipEvent_t ev0 = ev.a, ev1 = ev.b;
     PT_HIP_CHECK(hipEventRecord(ev0, st));
     DevMem mem(ctx);
     uint32_t* scal = nullptr; float* boxes = nullptr;
@@ -920,22 +949,23 @@ int pt_blas_build(PtContext* ctx, const void* vertices_dev, uint32_t vertex_stri
     PT_HIP_CHECK(hipGetLastError());
     PtBlas* b = new PtBlas();
     memset(b, 0, sizeof *b);
+    Owner<PtBlas, blas_free> owner(b);
     b->ctx = ctx; b->vertices = v; b->stride = vertex_stride; b->max_vertex = max_vertex;
     b->indices = indices_dev; b->prim_count = prim_count; b->max_leaf = max_leaf;
     int rc = pt_build_lbvh(ctx, boxes, prim_count, max_leaf, &b->nodes, &b->node_count, &b->leaf_prims, &b->sorted_keys);
-    if (rc) { delete b; return rc; }
+    if (rc) return rc;
     // The kernels traverse a binned-SAH tree (16-18 % fewer box tests than the Morton tree on the dragon
     // meshes); PT_HIP_TRAVERSAL_TREE=lbvh keeps the Morton tree for both purposes.
     const char* tree_env = getenv("PT_HIP_TRAVERSAL_TREE");
     const uint32_t* trav_order = b->leaf_prims;      // leaf order of the tree the kernels traverse
     if (!(tree_env && strcmp(tree_env, "lbvh") == 0) && prim_count > 1) {
         rc = pt_build_sah(ctx, boxes, prim_count, max_leaf, scal + 1, &b->trav_nodes, &b->trav_node_count, &b->trav_order);
-        if (rc) { pt_blas_destroy(b); return rc; }
+        if (rc) return rc;
         trav_order = b->trav_order;
         rc = pt_build_wide(ctx, b->trav_nodes, b->trav_node_count, &b->wide, &b->wide_count, &b->wide_depth);
     } else
         rc = pt_build_wide(ctx, b->nodes, b->node_count, &b->wide, &b->wide_count, &b->wide_depth);
-    if (rc) { pt_blas_destroy(b); return rc; }
+    if (rc) return rc;
     uint32_t host_scal[7];
     hipError_t e = hipMalloc((void**)&b->tris, sizeof(float4) * 3 * (size_t)prim_count);
     if (e == hipSuccess) {
@@ -944,22 +974,19 @@ int pt_blas_build(PtContext* ctx, const void* vertices_dev, uint32_t vertex_stri
     }
     if (e == hipSuccess) e = hipEventRecord(ev1, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e != hipSuccess) { pt_set_error("pt_blas_build: %s", hipGetErrorString(e)); pt_blas_destroy(b); return PT_ERROR_HIP; }
+    if (e != hipSuccess) { pt_set_error("pt_blas_build: %s", hipGetErrorString(e)); return PT_ERROR_HIP; }
     float maxabs; memcpy(&maxabs, &host_scal[0], 4);
     b->delta = maxabs * 3.0517578125e-05f;
     for (int k = 0; k < 3; ++k) { b->root_lo[k] = ord2f(host_scal[1 + k]); b->root_hi[k] = ord2f(host_scal[4 + k]); }
     (void)hipEventElapsedTime(&b->build_ms, ev0, ev1);
-    (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
-    *out = b;
+    *out = owner.release();
     return PT_OK;
 }
 
 int pt_blas_destroy(PtBlas* b)
 {
     if (!b) return PT_OK;
-    (void)hipFree(b->nodes); (void)hipFree(b->tris); (void)hipFree(b->leaf_prims); (void)hipFree(b->sorted_keys); (void)hipFree(b->wide);
-    (void)hipFree(b->trav_nodes); (void)hipFree(b->trav_order);
-    delete b;
+    blas_free(b);
     return PT_OK;
 }
 
@@ -1052,10 +1079,12 @@ int pt_tlas_build(PtContext* ctx, const PtInstance* instances, uint32_t n, PtTla
     PT_REQUIRE(n <= (1u << 24), "instance count exceeds the 24-bit custom index");
     PT_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    hipEvent_t ev0, ev1;
-    PT_HIP_CHECK(hipEventCreate(&ev0)); PT_HIP_CHECK(hipEventCreate(&ev1));
+    EventPair ev;
+    PT_HIP_CHECK(ev.create());
+    const hipEvent_t ev0 = ev.a, ev1 = ev.b;
     PT_HIP_CHECK(hipEventRecord(ev0, st));
     PtTlas* t = new PtTlas();
+    Owner<PtTlas, tlas_free> owner(t);        // nothing traverses a structure that is still being built
     t->ctx = ctx; t->n = n; t->nodes = nullptr; t->leaf_inst = nullptr; t->inst = nullptr; t->shade_inst = nullptr;
     t->pool_nodes = nullptr; t->pool_tris = nullptr; t->pool_node_count = 0;
     t->host_boxes.resize((size_t)n * 6); t->host_w2o.resize((size_t)n * 12);
@@ -1066,7 +1095,7 @@ int pt_tlas_build(PtContext* ctx, const PtInstance* instances, uint32_t n, PtTla
     for (uint32_t i = 0; i < n; ++i) {
         const PtInstance& I = instances[i];
         const PtBlas* b = (const PtBlas*)(uintptr_t)I.accelerationStructureReference;
-        if (!b) { delete t; pt_set_error("pt_tlas_build: instance %u has a null BLAS reference", i); return PT_ERROR_INVALID_ARGUMENT; }
+        if (!b) { pt_set_error("pt_tlas_build: instance %u has a null BLAS reference", i); return PT_ERROR_INVALID_ARGUMENT; }
         const float* m = I.transform;
         float w2o[12];
         invert_transform(m, w2o);
@@ -1106,11 +1135,11 @@ int pt_tlas_build(PtContext* ctx, const PtInstance* instances, uint32_t n, PtTla
     float* boxes_dev = nullptr;
     hipError_t e = hipMalloc((void**)&boxes_dev, sizeof(float) * 6 * (size_t)n);
     if (e == hipSuccess) e = hipMemcpyAsync(boxes_dev, t->host_boxes.data(), sizeof(float) * 6 * (size_t)n, hipMemcpyHostToDevice, st);
-    if (e != hipSuccess) { delete t; pt_set_error("pt_tlas_build: %s", hipGetErrorString(e)); return PT_ERROR_HIP; }
+    if (e != hipSuccess) { (void)hipFree(boxes_dev); pt_set_error("pt_tlas_build: %s", hipGetErrorString(e)); return PT_ERROR_HIP; }
     uint64_t* keys = nullptr;
     int rc = pt_build_lbvh(ctx, boxes_dev, n, 1, &t->nodes, &t->node_count, &t->leaf_inst, &keys);
     (void)hipFree(boxes_dev);
-    if (rc) { delete t; return rc; }
+    if (rc) return rc;
     (void)hipFree(keys);
     // pool: wide nodes of the TLAS followed by those of every distinct BLAS; triangles of every distinct BLAS
     {
@@ -1125,10 +1154,10 @@ int pt_tlas_build(PtContext* ctx, const PtInstance* instances, uint32_t n, PtTla
             if (k == uniq.size()) { uniq.push_back(b); tri_base.push_back(nt); nt += b->prim_count; }
             blas_of_inst[i] = (uint32_t)k;
         }
-        if (nt >= (1u << 28)) { pt_set_error("pt_tlas_build: more than 2^28 triangles in one TLAS"); pt_tlas_destroy(t); return PT_ERROR_LIMIT; }
+        if (nt >= (1u << 28)) { pt_set_error("pt_tlas_build: more than 2^28 triangles in one TLAS"); return PT_ERROR_LIMIT; }
         void* tlas_wide = nullptr;
         rc = pt_build_wide(ctx, t->nodes, t->node_count, &tlas_wide, &t->wide_count, &t->wide_depth);
-        if (rc) { pt_tlas_destroy(t); return rc; }
+        if (rc) return rc;
         uint32_t total_nodes = t->wide_count, depth_blas = 0;
         std::vector<uint32_t> root_of(uniq.size());
         for (size_t k = 0; k < uniq.size(); ++k) {
@@ -1138,7 +1167,7 @@ int pt_tlas_build(PtContext* ctx, const PtInstance* instances, uint32_t n, PtTla
         // a step pushes at most three references and an instance entry one
         if (3 * t->wide_depth + 1 + 3 * depth_blas > PT_LDS_STACK + PT_SPILL_STACK) {
             pt_set_error("pt_tlas_build: acceleration structure too deep for the traversal stack (%u + %u wide levels)", t->wide_depth, depth_blas);
-            (void)hipFree(tlas_wide); pt_tlas_destroy(t); return PT_ERROR_LIMIT;
+            (void)hipFree(tlas_wide); return PT_ERROR_LIMIT;
         }
         // What a ray that enters instance i continues with: the BLAS's root node, or, for a BLAS of
         // at most PT_TINY_BLAS triangles, one leaf over all of them (the instance's own box test has
@@ -1164,7 +1193,7 @@ int pt_tlas_build(PtContext* ctx, const PtInstance* instances, uint32_t n, PtTla
             e = hipMemcpyAsync(t->pool_tris + 3 * (size_t)tri_base[k], uniq[k]->tris, sizeof(float4) * 3 * (size_t)uniq[k]->prim_count, hipMemcpyDeviceToDevice, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         (void)hipFree(tlas_wide);
-        if (e != hipSuccess) { pt_set_error("pt_tlas_build: %s", hipGetErrorString(e)); pt_tlas_destroy(t); return PT_ERROR_HIP; }
+        if (e != hipSuccess) { pt_set_error("pt_tlas_build: %s", hipGetErrorString(e)); return PT_ERROR_HIP; }
         t->pool_node_count = total_nodes;
     }
     // instance records in the order of the TLAS leaves, so a leaf reference addresses its record
@@ -1183,10 +1212,9 @@ int pt_tlas_build(PtContext* ctx, const PtInstance* instances, uint32_t n, PtTla
     if (e == hipSuccess) e = hipMemcpyAsync(t->inst, di_sorted.data(), sizeof(PtDevInstance) * n, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipEventRecord(ev1, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e != hipSuccess) { pt_set_error("pt_tlas_build: %s", hipGetErrorString(e)); pt_tlas_destroy(t); return PT_ERROR_HIP; }
+    if (e != hipSuccess) { pt_set_error("pt_tlas_build: %s", hipGetErrorString(e)); return PT_ERROR_HIP; }
     (void)hipEventElapsedTime(&t->build_ms, ev0, ev1);
-    (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
-    *out = t;
+    *out = owner.release();
     return PT_OK;
 }
 
@@ -1194,10 +1222,7 @@ int pt_tlas_destroy(PtTlas* t)
 {
     if (!t) return PT_OK;
     (void)pt_lanes_sync(t->ctx);   // frames in flight traverse the pool
-    (void)hipFree(t->nodes); (void)hipFree(t->leaf_inst); (void)hipFree(t->inst); (void)hipFree(t->shade_inst);
-    for (auto& r : t->tri_records) (void)hipFree(r.dev);
-    (void)hipFree(t->pool_nodes); (void)hipFree(t->pool_tris);
-    delete t;
+    tlas_free(t);
     return PT_OK;
 }
 

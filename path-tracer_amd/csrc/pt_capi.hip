@@ -14,13 +14,18 @@ void pt_set_error(const char* fmt, ...)
     va_end(ap);
 }
 
+// Allocates and fills the new table first: a failed allocation or copy leaves the old table bound.
 template <typename T>
 static int replace_table(T** dst, uint32_t* n_dst, const T* src, uint32_t n)
 {
-    (void)hipFree(*dst); *dst = nullptr; *n_dst = 0;
-    PT_HIP_CHECK(hipMalloc((void**)dst, sizeof(T) * (n ? n : 1)));
-    if (n) PT_HIP_CHECK(hipMemcpy(*dst, src, sizeof(T) * n, hipMemcpyHostToDevice));
-    *n_dst = n;
+    T* fresh = nullptr;
+    PT_HIP_CHECK(hipMalloc((void**)&fresh, sizeof(T) * (n ? n : 1)));
+    if (n) {
+        hipError_t e = hipMemcpy(fresh, src, sizeof(T) * n, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipFree(fresh); pt_set_error("hipMemcpy failed: %s", hipGetErrorString(e)); return PT_ERROR_HIP; }
+    }
+    (void)hipFree(*dst);
+    *dst = fresh; *n_dst = n;
     return PT_OK;
 }
 
@@ -160,7 +165,7 @@ int pt_trace_fence(PtContext* c)
 int pt_ctx_set_max_paths(PtContext* c, uint64_t max_paths)
 {
     PT_REQUIRE(c, "null argument");
-    PT_REQUIRE(max_paths >= 64 && max_paths < (1ull << 32), "max_paths must be in [64, 2^32)");
+    PT_REQUIRE(max_paths >= 64 && max_paths < (1ull << 31), "max_paths must be in [64, 2^31)");
     c->max_paths = max_paths;
     return PT_OK;
 }

@@ -107,6 +107,8 @@ struct PtLane {
     bool pending = false;              // work enqueued since the last join
     uint64_t paths_cap = 0;            // slots per stream = kShards * shard_cap
     uint32_t shard_cap = 0;            // slots per shard (multiple of 64)
+    uint64_t shard_cap_wanted = 0;     // largest capacity ever asked for
+    bool rays_only = false;            // only q[0][0] and q[0][1] are allocated (pt_intersect)
     float4* q[2][4] = { { nullptr, nullptr, nullptr, nullptr }, { nullptr, nullptr, nullptr, nullptr } };
     PtHit* hits = nullptr;
     float4* path_result = nullptr;     // per path: final hitValue (xyz)

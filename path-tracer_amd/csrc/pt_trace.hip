@@ -612,7 +612,8 @@ int persistent_blocks(PtContext* ctx, const void* kernel)
     return ctx->num_cus * per_cu;
 }
 
-int ensure_workspace(PtContext* ctx, PtLane& l, uint64_t paths, uint64_t pixels)
+// rays_only: the two ray streams alone (pt_intersect writes its results to the caller's arrays).
+int ensure_workspace(PtContext* ctx, PtLane& l, uint64_t paths, uint64_t pixels, bool rays_only = false)
 {
     PtWorkspace& w = ctx->ws;
     if (!w.stats) {
@@ -626,16 +627,21 @@ int ensure_workspace(PtContext* ctx, PtLane& l, uint64_t paths, uint64_t pixels)
     }
     // per-shard capacity: the batches dealt to one shard, in slots
     const uint64_t groups = (paths + kDealPaths - 1) / kDealPaths;
-    const uint64_t cap = ((groups + kShards - 1) / kShards) * kDealPaths;
-    if (cap > l.shard_cap) {
+    uint64_t cap = ((groups + kShards - 1) / kShards) * kDealPaths;
+    if (cap > l.shard_cap || (!rays_only && l.rays_only)) {
         PT_HIP_CHECK(hipStreamSynchronize(l.stream));   // earlier work of this lane still uses the old queues
         for (int a = 0; a < 2; ++a) for (int k = 0; k < 4; ++k) { (void)hipFree(l.q[a][k]); l.q[a][k] = nullptr; }
         (void)hipFree(l.hits); (void)hipFree(l.path_result); l.hits = nullptr; l.path_result = nullptr;
         l.paths_cap = 0; l.shard_cap = 0;
+        if (cap < l.shard_cap_wanted) cap = l.shard_cap_wanted;      // a lane never shrinks
+        l.shard_cap_wanted = cap;
         const uint64_t slots = cap * kShards;
-        for (int a = 0; a < 2; ++a) for (int k = 0; k < 4; ++k) PT_HIP_CHECK(hipMalloc((void**)&l.q[a][k], sizeof(float4) * slots));
-        PT_HIP_CHECK(hipMalloc((void**)&l.hits, sizeof(PtHit) * slots));
-        PT_HIP_CHECK(hipMalloc((void**)&l.path_result, sizeof(float4) * slots));
+        l.rays_only = rays_only;
+        for (int a = 0; a < (rays_only ? 1 : 2); ++a) for (int k = 0; k < (rays_only ? 2 : 4); ++k) PT_HIP_CHECK(hipMalloc((void**)&l.q[a][k], sizeof(float4) * slots));
+        if (!rays_only) {
+            PT_HIP_CHECK(hipMalloc((void**)&l.hits, sizeof(PtHit) * slots));
+            PT_HIP_CHECK(hipMalloc((void**)&l.path_result, sizeof(float4) * slots));
+        }
         l.paths_cap = slots; l.shard_cap = (uint32_t)cap;
     }
     if (pixels > w.frame_pixels_cap) {
@@ -802,13 +808,14 @@ int pt_intersect(PtContext* ctx, const PtTlas* tlas, uint32_t n, const float* or
 {
     PT_REQUIRE(ctx && tlas && origins_dev && dirs_dev && hits_dev, "null argument");
     PT_REQUIRE(tlas->ctx == ctx, "the TLAS belongs to another context");
+    PT_REQUIRE(n < (1u << 31), "at most 2^31 - 1 rays per call (queue slots are 32-bit)");
     if (n == 0) return PT_OK;
     PT_HIP_CHECK(hipSetDevice(ctx->device));
     PtLane* lane = nullptr;
     int rc = pt_lane_begin(ctx, &lane);
     if (rc) return rc;
     PtLane& w = *lane;
-    if ((rc = ensure_workspace(ctx, w, n, 0))) return rc;
+    if ((rc = ensure_workspace(ctx, w, n, 0, true))) return rc;
     hipStream_t st = w.stream;
     PT_HIP_CHECK(hipMemsetAsync(w.counters, 0, sizeof(uint32_t) * kCounterWords, st));
     k_pack_rays<<<(n + kBlock - 1) / kBlock, kBlock, 0, st>>>(n, w.shard_cap, origins_dev, dirs_dev, w.q[0][0], w.q[0][1], w.counters);
@@ -839,14 +846,14 @@ int pt_trace(PtContext* ctx, const PtTlas* tlas, const float camera[32], uint32_
     uint64_t chunk_pixels = ctx->max_paths / spp;
     if (chunk_pixels < 1) chunk_pixels = 1;
     if (chunk_pixels > n_pixels) chunk_pixels = n_pixels;
-    PT_REQUIRE(chunk_pixels * spp < (1ull << 31), "max_paths too large");
+    if (chunk_pixels * spp >= (1ull << 31)) chunk_pixels = ((1ull << 31) - 1) / spp;   // slot indices are 32-bit
     const PtTlasView tv = view_of(tlas);
     PtPrimaryArg primary;
     memcpy(primary.camera.m, camera, sizeof primary.camera.m);
     primary.spp = spp; primary.W = width; primary.H = height; primary.frame = frame; primary.seed_mode = seed_mode;
     const int blocks_i = persistent_blocks(ctx, (const void*)k_intersect<false>);
-    const int blocks_p = persistent_blocks(ctx, (const void*)k_primary);
-    // whole multiples of kShards waves
+    // whole multiples of kShards waves (four waves per block): the passes that deal batches by index need them
+    const int blocks_p = std::max(16, persistent_blocks(ctx, (const void*)k_primary) / 16 * 16);
     const int blocks_s = std::max(16, persistent_blocks(ctx, (const void*)k_shade) * PT_SHADE_GRID / 16 * 16);
     // Every chunk of the frame goes to the next lane and is left in flight there; only the
     // read-modify-write of the image is chained, in submission order.

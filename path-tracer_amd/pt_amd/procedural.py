@@ -240,3 +240,48 @@ def stacked_copies(n_copies=6, n_tris=300, seed=5) -> Scene:
     model.materials = [mat]
     scene.add_model(model)
     return scene
+
+
+# Native sizes of the FlightHelmet base-colour maps (assets/helmet/FlightHelmet_baseColor*.png: 2048 x 2048 except
+# baseColor2 = LensesMat, 1024 x 1024), by the image index they have in a helmet scene imported on its own.
+HELMET_NATIVE_TEXTURE_SIZES = {1: 2048, 3: 1024, 6: 2048, 9: 2048}
+
+
+def upsample_texture(img, size):
+    """Deterministic enlargement of a square RGBA8 texture to size x size: every texel is repeated and a
+    small position-dependent pattern is added to the colour channels, so that no two neighbouring
+    texels are equal (an addressing error shows) while the image stays what it was."""
+    h, w = img.shape[:2]
+    assert h == w and size % w == 0
+    k = size // w
+    big = np.repeat(np.repeat(img, k, axis=0), k, axis=1).astype(np.int32)
+    y, x = np.mgrid[0:size, 0:size]
+    pattern = ((x * 7 + y * 13) & 7) - 4
+    big[..., :3] = np.clip(big[..., :3] + pattern[..., None], 0, 255)
+    return big.astype(np.uint8)
+
+
+def with_native_texture_sizes(helmet: Scene, sizes=None) -> Scene:
+    """A copy of a helmet scene whose sampled base-colour maps have the asset's native sizes
+    (4 x 16 MiB + 4 MiB of texels instead of the reduced fixtures)."""
+    import copy
+    out = copy.deepcopy(helmet)
+    for idx, size in (sizes or HELMET_NATIVE_TEXTURE_SIZES).items():
+        out.tables.images[idx] = upsample_texture(out.tables.images[idx], size)
+    return out
+
+
+# Where the composite scene puts the helmet and the dragon inside the Cornell box (world units of the box:
+# x in [-1.02, 1], y in [0, 1.99], z in [-1.04, 0.99]; camera at (0, 1, 3) looking down -z).
+COMPOSITE_HELMET_NODE = {"scale": [1.6, 1.6, 1.6], "translation": [0.42, 1.05, 0.35]}
+COMPOSITE_DRAGON_NODE = {"scale": [0.35, 0.35, 0.35], "translation": [-0.3, 0.45, -0.2]}
+
+
+def composite(cornell: Scene, helmet: Scene, dragon: Scene = None) -> Scene:
+    """Cornell box + FlightHelmet + dragon in one TLAS: 8 + 5 + 2 = 15 instances, in that order, the helmet
+    and the dragon hung under the root transforms above."""
+    import copy
+    scene = copy.deepcopy(cornell)
+    scene.merge(helmet, _trs_matrix(COMPOSITE_HELMET_NODE), "helmet")
+    scene.merge(dragon if dragon is not None else dragon_standin(), _trs_matrix(COMPOSITE_DRAGON_NODE), "dragon")
+    return scene

@@ -117,6 +117,34 @@ class Scene:
                     out.append(InstanceRef(mi, ni, mesh, model.world_matrix(ni)))
         return out
 
+    def merge(self, other, root_matrix=None, name="merged"):
+        """Appends the models of `other` (a deep copy: `other` is left as it was) with its images and
+        materials renumbered into this scene's tables, each model's node tree hung under a new root
+        node with `root_matrix`.  Instance order stays the reference's: models in the order they were
+        added, nodes depth first (source/renderer.cpp:457-470)."""
+        import copy
+        img_map = {0: 0, 0xFFFF: 0xFFFF}
+        for i, img in enumerate(other.tables.images):
+            if i > 0:
+                img_map[i] = self.tables.create_image(img.copy())
+        mat_map = {0xFFFF: 0xFFFF}
+        for i, m in enumerate(other.tables.materials):
+            m2 = np.array(m, dtype=abi.MATERIAL)
+            for f in ("albedoMapIndex", "mrMapIndex", "normalMapIndex", "occlusionMapIndex", "emissiveMapIndex"):
+                m2[f] = img_map.get(int(m[f]), 0xFFFF)
+            mat_map[i] = self.tables.create_material(m2)
+        root = np.eye(4, dtype=f32) if root_matrix is None else np.asarray(root_matrix, dtype=f32)
+        for mi, model in enumerate(other.models):
+            m = copy.deepcopy(model)
+            for mesh in m.meshes:
+                mesh.material = mat_map.get(mesh.material, 0xFFFF)
+            m.materials = [mat_map.get(x, 0xFFFF) for x in m.materials]
+            m.textures = [img_map.get(x, 0xFFFF) for x in m.textures]
+            m.nodes = [Node(f"{name}_root{mi}", None, root.copy(), [])] + \
+                      [Node(n.name, 0 if n.parent is None else n.parent + 1, n.local_matrix, list(n.meshes)) for n in m.nodes]
+            self.add_model(m)
+        return self
+
     def triangle_count(self):
         return sum(m.meshes[i.mesh].index_count // 3 for i in self.instances() for m in [self.models[i.model]])
 

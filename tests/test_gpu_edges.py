@@ -1,5 +1,6 @@
 """Edge cases of the hot path on the GPU against the oracle: degenerate rays, the smallest and the
-flattest acceleration structures, degenerate triangles, and the composite scene at 3840x2160."""
+flattest acceleration structures, degenerate triangles, and the composite scene (Cornell box, helmet,
+dragon) at 3840x2160."""
 import numpy as np
 import pytest
 
@@ -100,50 +101,46 @@ def test_single_triangle_and_degenerate_triangles(schedule, monkeypatch):
     assert len(hit45) and np.all(hit45["primitive"] == 4)
 
 
-def _composite(cornell):
-    """Cornell box + the dragon stand-in + a triangle soup inside it: 8 + 2 + 5 = 15 instances."""
-    import copy
-    from pt_amd import procedural
-    from pt_amd.gltf import _trs_matrix
-    scene = copy.deepcopy(cornell)
-    procedural.dragon_standin(scene)
-    scene.models[-1].nodes[0].local_matrix = _trs_matrix({"scale": [0.35, 0.35, 0.35], "translation": [-0.3, 0.45, -0.2]})
-    soup = procedural.triangle_soup(3000, seed=9, extent=0.3, size=0.05, n_instances=5)
-    m = soup.models[0]
-    base = len(scene.tables.materials)
-    scene.tables.materials.extend(soup.tables.materials)
-    for mesh in m.meshes:
-        mesh.material += base
-    from pt_amd.scene import Node, f32
-    root = Node("soup_root", None, _trs_matrix({"scale": [0.5, 0.5, 0.5], "translation": [0.4, 1.2, 0.1]}), [])
-    m.nodes = [root] + [Node(n.name, 0, n.local_matrix, n.meshes) for n in m.nodes]
-    scene.add_model(m)
-    return scene
+def _primary_rays(O, cam, W, H, px, py):
+    o = np.zeros((len(px), 3), np.float32); d = np.zeros((len(px), 3), np.float32)
+    for k in range(len(px)):
+        o[k], d[k] = O.primary_ray(cam, W, H, int(px[k]), int(py[k]))
+    return o, d
 
 
-def test_composite_scene_at_2160p(cornell):
-    """15 instances with nested transforms at 3840x2160: bounce-0 ids of a sample of primary rays
-    equal the oracle's, every path is accounted for, two chunked frames in flight included."""
+def test_composite_scene_at_2160p(cornell, helmet, dragon):
+    """BASELINE config 5's scene (Cornell box + FlightHelmet + dragon stand-in: 8 + 5 + 2 = 15 instances under
+    nested transforms, the helmet's base-colour maps bound) at 3840x2160: hit records of primary rays over
+    the whole image and over the helmet equal the oracle's and the brute force's, textured helmet
+    instances are among them, every path of two chunked frames in flight is accounted for, and a strip
+    of the second frame that contains helmet pixels equals the oracle's bit for bit."""
     import oracle as O
-    from pt_amd import camera, hip
-    scene = _composite(cornell)
-    assert len(scene.instances()) == 15
+    from pt_amd import camera, hip, procedural
+    scene = procedural.composite(cornell, helmet, dragon)
+    insts = scene.instances()
+    assert len(insts) == 15 and scene.triangle_count() == 32 + 94722 + 134995
+    mats = scene.tables.material_array()
+    textured = {i for i, it in enumerate(insts) if mats[scene.models[it.model].meshes[it.mesh].material]["useAlbedoMap"]}
+    helmet_textured = textured & set(range(8, 13))
+    assert len(helmet_textured) == 4 and 13 in textured
     W, H = 3840, 2160
     orc = O.OracleScene(scene)
     r = hip.Renderer(scene, W, H)
     try:
         cam = camera.camera_uniform(W, H)
         rng = np.random.default_rng(1)
-        px = rng.integers(0, W, size=20000); py = rng.integers(0, H, size=20000)
-        o = np.zeros((len(px), 3), np.float32); d = np.zeros((len(px), 3), np.float32)
-        for k in range(len(px)):
-            o[k], d[k] = O.primary_ray(cam, W, H, int(px[k]), int(py[k]))
+        px = np.concatenate([rng.integers(0, W, size=20000), rng.integers(2064, 2432, size=8000)])
+        py = np.concatenate([rng.integers(0, H, size=20000), rng.integers(880, 1600, size=8000)])
+        o, d = _primary_rays(O, cam, W, H, px, py)
         hg, tg = r.intersect(o, d)
         ho, to = orc.tlas.intersect(o, d)
         assert np.array_equal(hg, ho) and _float_eq(tg, to)
-        hb, tb = orc.tlas.intersect(o[:300], d[:300], use_bvh=False)
-        assert np.array_equal(hb, ho[:300]) and _float_eq(tb, to[:300])
-        assert len(set(ho["instance"].tolist()) - {0xFFFFFFFF}) >= 10
+        sub = np.concatenate([np.arange(150), 20000 + np.arange(150)])
+        hb, tb = orc.tlas.intersect(o[sub], d[sub], use_bvh=False)
+        assert np.array_equal(hb, ho[sub]) and _float_eq(tb, to[sub])
+        seen = set(ho["instance"].tolist()) - {0xFFFFFFFF}
+        assert len(seen) >= 13 and helmet_textured <= seen
+        assert np.isin(ho["instance"], list(helmet_textured)).sum() > 500
         r.ctx.set_max_paths(5_000_000)
         for frame in range(2):
             r.render(spp=2, frame=frame)
@@ -151,8 +148,16 @@ def test_composite_scene_at_2160p(cornell):
         assert int(s["paths"]) == 2 * W * H * 2 and int(s["rays_per_depth"][0]) == 2 * W * H * 2
         res = r.last_result()
         assert np.isfinite(res).all() and (res >= 0).all()
-        # a strip of the second frame against the oracle
-        want, _ = orc.render_frame(cam, W, H, frame=1, spp=2, rect=(1800, 1000, 2056, 1064), threads=8)
-        assert _float_eq(res[1000:1064, 1800:2056], want[1000:1064, 1800:2056])
+        # a strip of the second frame across the helmet against the oracle; its paths do hit textured surfaces
+        x0, y0, x1, y1 = 2080, 1000, 2400, 1048
+        want, st = orc.render_frame(cam, W, H, frame=1, spp=2, rect=(x0, y0, x1, y1), threads=8)
+        assert int(st["tex_hits"]) > 2000
+        assert _float_eq(res[y0:y1, x0:x1], want[y0:y1, x0:x1])
+        # the helmet's pixels are not grey: its maps really are sampled
+        oh, dh = _primary_rays(O, cam, W, H, np.tile(np.arange(x0, x1), 2), np.repeat([y0, y1 - 1], x1 - x0))
+        on_helmet = np.isin(orc.tlas.intersect(oh, dh)[0]["instance"], list(helmet_textured)).reshape(2, x1 - x0)
+        assert on_helmet.sum() > 50
+        rows = res[[y0, y1 - 1], x0:x1][on_helmet]
+        assert np.mean(np.abs(rows[:, 0] - rows[:, 2])) > 1e-3
     finally:
         r.close()

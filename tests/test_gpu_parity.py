@@ -330,12 +330,16 @@ def test_frames_in_flight_keep_submission_order(mode, cornell):
         assert _float_eq(images[1], images[3])
 
 
-def test_full_size_properties_1080p(dragon):
-    """BASELINE size (1080p): properties that need no oracle run -- every path accounted for,
-    one primary ray per path, monotone ray counts per bounce, finite non-negative radiance,
-    and sample-count linearity of the float sum."""
+@pytest.mark.parametrize("name,strip", [("dragon", (800, 500, 1056, 532)), ("cornell", (700, 520, 1212, 552)), ("cube", (832, 600, 1088, 632))])
+def test_full_size_properties_1080p(name, strip, request):
+    """BASELINE size (1920x1080) for the dragon, the Cornell box and the cube: properties that need no
+    oracle run -- every path accounted for, one primary ray per path, monotone ray counts per bounce,
+    finite non-negative radiance, sample-count linearity of the float sum -- and a strip of the frame
+    against the oracle, bit for bit."""
+    from pt_amd import camera
+    scene = request.getfixturevalue(name)
     w, h, spp = 1920, 1080, 2
-    r = _renderer(dragon, w, h)
+    r = _renderer(scene, w, h)
     try:
         r.render(spp=spp, frame=0)
         s = r.stats()
@@ -345,9 +349,44 @@ def test_full_size_properties_1080p(dragon):
         assert np.all(np.diff(rp) <= 0)
         res = r.last_result()
         assert np.isfinite(res).all() and (res >= 0).all()
+        x0, y0, x1, y1 = strip
+        want, st = _oracle(scene).render_frame(camera.camera_uniform(w, h), w, h, frame=0, spp=spp, rect=strip, threads=8)
+        assert int(st["hits"]) > (x1 - x0) * (y1 - y0) // 4          # the strip lies on the scene, not on the background
+        assert _float_eq(res[y0:y1, x0:x1], want[y0:y1, x0:x1])
         r.render(spp=spp, frame=1)
         acc = r.accum_host()
         assert np.all(acc[..., 3] == 2.0)
+    finally:
+        r.close()
+
+
+def test_helmet_native_texture_footprint_1080p(helmet):
+    """BASELINE config 3 at the footprint of the asset: the helmet's four sampled base-colour maps at their
+    native 2048 x 2048 / 1024 x 1024 (52 MiB of texels on the device; the committed fixture holds them
+    reduced, they are enlarged here by a fixed rule), 1920x1080 with a camera that frames the helmet:
+    path bookkeeping, and a strip across the helmet against the oracle, bit for bit."""
+    from pt_amd import camera, procedural
+    scene = procedural.with_native_texture_sizes(helmet)
+    sizes = sorted(im.shape[0] for im in scene.tables.images if im.shape[0] > 2)
+    assert sizes == [1024, 2048, 2048, 2048]
+    W, H, spp = 1920, 1080, 4
+    cam = camera.camera_uniform(W, H, **HELMET_CAMERA)
+    r = _renderer(scene, W, H, camera=cam)
+    try:
+        assert sorted(int(t["width"]) for t in r.textures if t["width"] > 2) == sizes
+        r.render(spp=spp, frame=0)
+        s = r.stats()
+        assert int(s["paths"]) == W * H * spp and int(s["rays_per_depth"][0]) == W * H * spp
+        res = r.last_result()
+        assert np.isfinite(res).all() and (res >= 0).all()
+        strip = (640, 500, 1280, 524)
+        want, st = _oracle(scene).render_frame(cam, W, H, frame=0, spp=spp, rect=strip, threads=8)
+        assert int(st["tex_hits"]) > 5000
+        x0, y0, x1, y1 = strip
+        assert _float_eq(res[y0:y1, x0:x1], want[y0:y1, x0:x1])
+        # enlarging changed what is sampled: the reduced maps give another image
+        want_small, _ = _oracle(helmet).render_frame(cam, W, H, frame=0, spp=spp, rect=strip, threads=8)
+        assert not _float_eq(want[y0:y1, x0:x1], want_small[y0:y1, x0:x1])
     finally:
         r.close()
 

@@ -7,7 +7,11 @@ usage: tools/pmc_traffic.py <pmc dir> <bench args recorded with the result...>  
 import csv
 import glob
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import source_hash
 
 d = sys.argv[1]
 tot = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "SQ_INSTS_VALU": 0.0}
@@ -25,4 +29,5 @@ print(json.dumps({"kernel": "k_intersect + k_primary", "launches": n, "fetch_byt
                   "bytes_per_launch": (fetch + write) / n, "corrections": "FETCH_SIZE KiB x 1024 x 2 (gfx950), WRITE_SIZE KiB x 1024",
                   # wave64 vector instructions the two kernels execute per launch (the SQ pass of the same workload)
                   "valu_insts_per_launch": tot["SQ_INSTS_VALU"] / launches["SQ_INSTS_VALU"] if launches["SQ_INSTS_VALU"] == n else None,
+                  "source_hash": source_hash(),      # the kernel sources the counters belong to
                   "command": "bench.py " + " ".join(sys.argv[2:])}))
