@@ -242,6 +242,17 @@ int pt_ctx_set_max_paths(PtContext* ctx, uint64_t max_paths);
  * source/swap_chain.cpp:122-133). */
 int pt_accum_resolve(PtContext* ctx, const float* accum_sum_dev, uint32_t n_pixels, uint8_t* rgba8_dev, int bgra);
 
+/* Multi-GPU in one process: sums the float accumulation images (PT_ACCUM_SUM_F32, n_pixels float4
+ * each) of n contexts, one per GPU, so that every image holds the total.  The reference renders on one
+ * device (source/vulkan_context.cpp:218-286); this is the exchange step of samples-per-pixel
+ * sharding: context r traces frames r, r + n, r + 2n, ... into accum_sum_dev[r], then one call here.
+ * It goes over xGMI peer access directly, every link at once: GPU r sums slice r of all images in the
+ * order of the contexts (the result is the same bits on every GPU and from run to run) and every GPU
+ * then copies the other slices from their owners.  Asynchronous: each context's stream waits for its
+ * frames in flight and for the other contexts; pt_sync a context before reading its image on the host.
+ * n <= 16; contexts may share a device (rehearsal on one GPU); devices must have peer access. */
+int pt_accum_allreduce(PtContext* const* ctxs, void* const* accum_sum_dev, uint32_t n, uint32_t n_pixels);
+
 #ifdef __cplusplus
 }
 #endif

@@ -148,7 +148,10 @@ __device__ __forceinline__ void pt_primary_seed(const PtPrimaryArg& P, uint32_t 
 {
     const uint32_t in_chunk = q / P.spp, s = q % P.spp, pixel = P.pixel0 + in_chunk;
     const uint32_t px = pixel % P.W, py = pixel / P.W;
-    const uint32_t v1 = P.seed_mode == PT_SEED_CLOCK ? (uint32_t)clock64() : P.frame * P.spp + s;
+    // the reference reads the clock once per sample inside a pixel's loop, so successive samples see successive
+    // values; here a pixel's samples are lanes that read the (wave-uniform) clock together, and the sample index
+    // is added so that they still differ
+    const uint32_t v1 = P.seed_mode == PT_SEED_CLOCK ? (uint32_t)clock64() + s : P.frame * P.spp + s;
     seed = pt_tea(py * P.W + px, v1);
     result_slot = q;
 }
@@ -987,6 +990,97 @@ int pt_accum_resolve(PtContext* ctx, const float* accum_sum_dev, uint32_t n_pixe
 }
 
 } // extern "C"
+
+// ---- sum of the accumulation images of several contexts over peer access ------------------------
+namespace {
+constexpr uint32_t kMaxPeers = 16;
+struct PtPeerImages { float4* img[kMaxPeers]; };
+
+// out[i] = img[0][i] + img[1][i] + ... in this order, for i in [begin, end); out is img[self]
+__global__ void k_sum_peers(PtPeerImages P, uint32_t n, uint32_t self, uint32_t begin, uint32_t end)
+{
+    const uint32_t i = begin + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= end) return;
+    float4 a = P.img[0][i];
+    for (uint32_t k = 1; k < n; ++k) { const float4 b = P.img[k][i]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+    P.img[self][i] = a;
+}
+__global__ void k_copy_peer(const float4* __restrict__ src, float4* __restrict__ dst, uint32_t begin, uint32_t end)
+{
+    const uint32_t i = begin + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < end) dst[i] = src[i];
+}
+} // namespace
+
+extern "C" int pt_accum_allreduce(PtContext* const* ctxs, void* const* accum, uint32_t n, uint32_t n_pixels)
+{
+    PT_REQUIRE(ctxs && accum && n >= 1 && n <= kMaxPeers, "1 to 16 contexts");
+    for (uint32_t r = 0; r < n; ++r) PT_REQUIRE(ctxs[r] && accum[r], "null context or image");
+    for (uint32_t r = 0; r < n; ++r) for (uint32_t k = 0; k < r; ++k) PT_REQUIRE(accum[r] != accum[k], "two contexts share one image");
+    if (n == 1 || n_pixels == 0) return PT_OK;
+    // peer access, both directions, once per pair of distinct devices
+    for (uint32_t r = 0; r < n; ++r) {
+        PT_HIP_CHECK(hipSetDevice(ctxs[r]->device));
+        for (uint32_t k = 0; k < n; ++k) {
+            if (ctxs[k]->device == ctxs[r]->device) continue;
+            int can = 0;
+            PT_HIP_CHECK(hipDeviceCanAccessPeer(&can, ctxs[r]->device, ctxs[k]->device));
+            if (!can) { pt_set_error("pt_accum_allreduce: device %d cannot access device %d", ctxs[r]->device, ctxs[k]->device); return PT_ERROR_HIP; }
+            const hipError_t e = hipDeviceEnablePeerAccess(ctxs[k]->device, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { pt_set_error("hipDeviceEnablePeerAccess: %s", hipGetErrorString(e)); return PT_ERROR_HIP; }
+            (void)hipGetLastError();
+        }
+    }
+    PtPeerImages P;
+    for (uint32_t k = 0; k < kMaxPeers; ++k) P.img[k] = k < n ? (float4*)accum[k] : nullptr;
+    std::vector<hipEvent_t> ev(2 * n, nullptr);
+    auto cleanup = [&]() { for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e); };
+    auto fail = [&](hipError_t e, const char* what) { pt_set_error("pt_accum_allreduce: %s: %s", what, hipGetErrorString(e)); cleanup(); return (int)PT_ERROR_HIP; };
+    hipError_t e = hipSuccess;
+    // every image is complete on its own stream ...
+    for (uint32_t r = 0; r < n; ++r) {
+        if ((e = hipSetDevice(ctxs[r]->device)) != hipSuccess) return fail(e, "hipSetDevice");
+        int rc = pt_lanes_join(ctxs[r]);
+        if (rc) { cleanup(); return rc; }
+        if ((e = hipEventCreateWithFlags(&ev[r], hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreate");
+        if ((e = hipEventCreateWithFlags(&ev[n + r], hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreate");
+        if ((e = hipEventRecord(ev[r], ctxs[r]->stream)) != hipSuccess) return fail(e, "hipEventRecord");
+    }
+    // ... before anyone reads it: GPU r sums slice r
+    const uint32_t per = (n_pixels + n - 1) / n;
+    for (uint32_t r = 0; r < n; ++r) {
+        if ((e = hipSetDevice(ctxs[r]->device)) != hipSuccess) return fail(e, "hipSetDevice");
+        for (uint32_t k = 0; k < n; ++k) if (k != r && (e = hipStreamWaitEvent(ctxs[r]->stream, ev[k], 0)) != hipSuccess) return fail(e, "hipStreamWaitEvent");
+        const uint32_t b = std::min(n_pixels, r * per), t = std::min(n_pixels, b + per);
+        if (t > b) k_sum_peers<<<(t - b + kBlock - 1) / kBlock, kBlock, 0, ctxs[r]->stream>>>(P, n, r, b, t);
+        if ((e = hipEventRecord(ev[n + r], ctxs[r]->stream)) != hipSuccess) return fail(e, "hipEventRecord");
+    }
+    // every GPU fetches the other slices from their owners
+    for (uint32_t r = 0; r < n; ++r) {
+        if ((e = hipSetDevice(ctxs[r]->device)) != hipSuccess) return fail(e, "hipSetDevice");
+        for (uint32_t k = 0; k < n; ++k) if (k != r && (e = hipStreamWaitEvent(ctxs[r]->stream, ev[n + k], 0)) != hipSuccess) return fail(e, "hipStreamWaitEvent");
+        for (uint32_t k = 0; k < n; ++k) {
+            if (k == r) continue;
+            const uint32_t b = std::min(n_pixels, k * per), t = std::min(n_pixels, b + per);
+            if (t > b) k_copy_peer<<<(t - b + kBlock - 1) / kBlock, kBlock, 0, ctxs[r]->stream>>>(P.img[k], P.img[r], b, t);
+        }
+    }
+    // a later call must not overwrite slice k of image k while GPU r still copies it: every stream waits for
+    // every copy.  The events are recorded again for that and destroyed at once (the runtime keeps them alive
+    // until they have completed).
+    for (uint32_t r = 0; r < n; ++r) {
+        if ((e = hipSetDevice(ctxs[r]->device)) != hipSuccess) return fail(e, "hipSetDevice");
+        if ((e = hipEventRecord(ev[r], ctxs[r]->stream)) != hipSuccess) return fail(e, "hipEventRecord");
+    }
+    for (uint32_t r = 0; r < n; ++r) {
+        if ((e = hipSetDevice(ctxs[r]->device)) != hipSuccess) return fail(e, "hipSetDevice");
+        for (uint32_t k = 0; k < n; ++k) if (k != r && (e = hipStreamWaitEvent(ctxs[r]->stream, ev[k], 0)) != hipSuccess) return fail(e, "hipStreamWaitEvent");
+    }
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail(e, "kernel launch");
+    cleanup();
+    return PT_OK;
+}
 
 #ifdef PT_SCHED_STATS
 extern "C" int pt_debug_sched_stats(unsigned long long* out8, int reset)

@@ -38,6 +38,21 @@ void Renderer::Render()
     _renderedFrames++;
 }
 
+void Renderer::Render(uint32_t frameIndex)
+{
+    PtCheckResult(pt_trace(_context->Handle(), _tlas->Structure(), _cameraData.viewInverse, _windowWidth, _windowHeight, frameIndex,
+                           _info.samplesPerFrame, _info.maxDepth, _info.seedMode, _info.accumMode, _renderTarget),
+                  "Failed tracing rays!");
+    _renderedFrames++;
+}
+
+std::vector<float> Renderer::ReadAccumulation() const
+{
+    std::vector<float> out(size_t(_windowWidth) * _windowHeight * 4);
+    if (_info.accumMode != PT_ACCUM_MEAN_UNORM8) _context->Download(_renderTarget, out.size() * sizeof(float), out.data());
+    return out;
+}
+
 void Renderer::InitializeRenderTarget()
 {
     const size_t pixels = size_t(_windowWidth) * _windowHeight;
@@ -121,11 +136,8 @@ std::vector<uint8_t> Renderer::ReadImageRGBA8() const
     if (_info.accumMode == PT_ACCUM_MEAN_UNORM8) { _context->Download(_renderTarget, out.size(), out.data()); return out; }
     std::vector<uint8_t> zeros(pixels * 4, 0);
     void* rgba = _context->Upload(zeros.data(), zeros.size());
-    if (_info.accumMode == PT_ACCUM_SUM_F32) PtCheckResult(pt_accum_resolve(_context->Handle(), static_cast<const float*>(_renderTarget), static_cast<uint32_t>(pixels), static_cast<uint8_t*>(rgba), 0), "Failed resolving!");
-    else {
-        // running mean: alpha is 1, so the resolve divides by one
-        PtCheckResult(pt_accum_resolve(_context->Handle(), static_cast<const float*>(_renderTarget), static_cast<uint32_t>(pixels), static_cast<uint8_t*>(rgba), 0), "Failed resolving!");
-    }
+    // float sum: rgb / alpha; float running mean: alpha is 1, so the same resolve divides by one
+    PtCheckResult(pt_accum_resolve(_context->Handle(), static_cast<const float*>(_renderTarget), static_cast<uint32_t>(pixels), static_cast<uint8_t*>(rgba), 0), "Failed resolving!");
     _context->Download(rgba, out.size(), out.data());
     _context->Free(rgba);
     return out;

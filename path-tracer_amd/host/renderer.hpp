@@ -23,12 +23,17 @@ public:
     Renderer& operator=(const Renderer&) = delete;
 
     void Render();
+    // Multi-GPU: renderer r of N traces frames r, r + N, ... of the same image, so the frame index is the caller's.
+    void Render(uint32_t frameIndex);
 
     // headless additions: results come back through these instead of a swapchain
     [[nodiscard]] std::vector<float> LastFrameResult() const;        // width*height*3, value of `result` in ray_gen.rgen:74
     [[nodiscard]] std::vector<uint8_t> ReadImageRGBA8() const;       // resolved accumulation target
     [[nodiscard]] PtTraceStats Stats() const;
     [[nodiscard]] uint32_t RenderedFrames() const { return _renderedFrames; }
+    [[nodiscard]] void* RenderTarget() const { return _renderTarget; }           // device pointer of the accumulation image
+    [[nodiscard]] std::vector<float> ReadAccumulation() const;                   // float sum / mean image, width*height*4
+    [[nodiscard]] const std::shared_ptr<HipContext>& Context() const { return _context; }
 
 private:
     struct CameraUniformData { float viewInverse[16]; float projInverse[16]; };   // include/renderer.hpp:31-35

@@ -60,6 +60,7 @@ SIGNATURES = {
     "pt_ctx_set_profiling": (_i, [_vp, _i]),
     "pt_trace_profile": (_i, [_vp, _vp]),
     "pt_accum_resolve": (_i, [_vp, _vp, _u32, _vp, _i]),
+    "pt_accum_allreduce": (_i, [_vp, _vp, _u32, _u32]),
 }
 
 _lib = None
@@ -146,6 +147,14 @@ class Context:
             self.close()
         except Exception:
             pass
+
+
+def accum_allreduce(contexts, accum_ptrs, n_pixels):
+    """pt_accum_allreduce over several contexts of this process (one per GPU): every float sum image ends up holding the total."""
+    n = len(contexts)
+    cs = (C.c_void_p * n)(*[c.h for c in contexts])
+    ps = (C.c_void_p * n)(*accum_ptrs)
+    _check(load_library().pt_accum_allreduce(cs, ps, n, n_pixels))
 
 
 class BottomLevelAccelerationStructure:
