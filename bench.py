@@ -31,13 +31,12 @@ VALU_PEAK_PER_SIMD = 0.5  # wave64 vector instructions per cycle per SIMD: 157.3
 
 
 def source_hash():
-    """Identifies the kernel sources a PMC record was collected with."""
+    """Identifies the sources of the tracing kernels and of the traversal layout a PMC record was collected with."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "path-tracer_amd", "csrc")
-    for name in sorted(os.listdir(d)):
-        if name.endswith((".hip", ".h")):
-            with open(os.path.join(d, name), "rb") as f:
-                h.update(name.encode() + b"\0" + f.read())
+    for name in ("pt_trace.hip", "pt_device.h", "pt_traverse_sched.h", "pt_internal.h", "pt_wide.h", "pt_sah.h"):
+        with open(os.path.join(d, name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
     return h.hexdigest()[:16]
 
 

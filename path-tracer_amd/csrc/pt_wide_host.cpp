@@ -270,6 +270,8 @@ void pt_wide4_simulate_host(const void* wide, const float* tris, uint32_t n_rays
             for (int i = 1; i < nh; ++i) for (int j = i; j > 0 && tn[j] < tn[j - 1]; --j) { std::swap(tn[j], tn[j - 1]); std::swap(rf[j], rf[j - 1]); }
             for (int i = nh - 1; i >= 0; --i) stack.push_back(rf[i]);
             deepest = stack.size() > deepest ? stack.size() : deepest;
+            // stats[3 + k]: node steps that leave k or more entries below the child taken next (k = 1..20)
+            if (order == 0) for (size_t k = 1; k <= 20 && k + 1 <= stack.size(); ++k) ++stats[3 + k];
         }
         if (deepest > stats[2]) stats[2] = deepest;
         if (t_out) t_out[r] = (float)best;

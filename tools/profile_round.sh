@@ -1,24 +1,39 @@
 #!/bin/bash
 # Collects what profiles/ holds for one build: the default bench line, the rocprofv3 kernel stats of
-# the same command, and the PMC passes (one rocprofv3 run per counter group).
-# usage (on the GPU box): tools/profile_round.sh <tag>
+# the same command and of the one-frame-at-a-time run, the PMC passes (one rocprofv3 run per counter
+# group) and the per-configuration lines of BASELINE.md.
+# usage (on the GPU box): tools/profile_round.sh <tag>     (SKIP_PMC=1, SKIP_CONFIGS=1 to shorten)
 set -u
 tag=$1
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/$tag
 mkdir -p $out
-timeout -k 10 400 python3 bench.py > $out/bench.json 2> $out/bench.err || { tail -5 $out/bench.err; exit 1; }
-tail -c 600 $out/bench.json; echo
-timeout -k 10 400 python3 bench.py --scene cornell > $out/bench_cornell.json 2> $out/bench_cornell.err || { tail -5 $out/bench_cornell.err; exit 1; }
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --no-serial-roofline > $out/trace_bench.json 2> $out/trace.err || { tail -5 $out/trace.err; exit 1; }
-cp $(ls $out/trace/*/*kernel_stats.csv | head -1) $out/kernel_stats.csv
-# the same with one frame in flight: every launch has the GPU to itself
-timeout -k 10 400 python3 bench.py --frames-in-flight 1 --no-cpu-baseline > $out/bench_serial.json 2> $out/bench_serial.err || { tail -5 $out/bench_serial.err; exit 1; }
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_serial -- python3 bench.py --frames-in-flight 1 --no-cpu-baseline > $out/trace_serial_bench.json 2> $out/trace_serial.err || { tail -5 $out/trace_serial.err; exit 1; }
-cp $(ls $out/trace_serial/*/*kernel_stats.csv | head -1) $out/kernel_stats_serial.csv
+run() { local name=$1; shift; timeout -k 10 500 "$@" > $out/$name.json 2> $out/$name.err || { echo "$name failed"; tail -5 $out/$name.err; exit 1; }; }
+prof() { local name=$1; shift; timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_$name -- "$@" > $out/trace_$name.json 2> $out/trace_$name.err || { echo "trace $name failed"; tail -5 $out/trace_$name.err; exit 1; }
+                               cp $(ls $out/trace_$name/*/*kernel_stats.csv | head -1) $out/${name}_kernel_stats.csv; }
+run bench python3 bench.py
+tail -c 400 $out/bench.json; echo
+prof default python3 bench.py --no-serial-roofline --no-secondary --no-cpu-baseline
+# one frame at a time: every launch has the GPU to itself
+run serial_bench python3 bench.py --frames-in-flight 1 --no-cpu-baseline --no-secondary
+prof serial python3 bench.py --frames-in-flight 1 --no-cpu-baseline --no-secondary
+if [ -z "${SKIP_CONFIGS:-}" ]; then
+  # BASELINE.json's configurations on one GPU (config 4 and 5 at a reduced sample count: they are multi-GPU runs)
+  run cfg1_cornell_512 python3 bench.py --scene cornell --width 512 --height 512 --spp 16 --steps 1 --warmup 1 --frames-in-flight 1 --no-secondary
+  run cfg2_cornell_1080p python3 bench.py --scene cornell --spp 256 --steps 4 --frames-in-flight 1 --no-secondary
+  run cfg2_cube_1080p python3 bench.py --scene cube --spp 256 --steps 4 --frames-in-flight 1 --no-secondary
+  run cfg3_helmet_1080p python3 bench.py --scene helmet --total-spp 1024 --frames-in-flight 1 --no-secondary
+  run cfg4_dragon_1080p_4096spp python3 bench.py --total-spp 4096 --no-secondary --no-cpu-baseline
+  run cfg5_composite_2160p python3 bench.py --scene composite --width 3840 --height 2160 --spp 64 --total-spp 256 --frames-in-flight 1 --no-secondary --cpu-spp 2
+  for c in cornell cube helmet composite; do
+    case $c in composite) extra="--width 3840 --height 2160 --spp 64";; *) extra="";; esac
+    prof cfg_$c python3 bench.py --scene $c $extra --steps 3 --warmup 1 --frames-in-flight 1 --no-cpu-baseline --no-secondary
+  done
+fi
 [ -n "${SKIP_PMC:-}" ] && { echo done; exit 0; }
-bash tools/pmc_passes.sh $out/pmc --steps 3 --warmup 3 > $out/pmc.log 2>&1 || { tail -5 $out/pmc.log; exit 1; }
-bash tools/pmc_passes2.sh $out/pmc2 --steps 3 --warmup 3 >> $out/pmc.log 2>&1 || { tail -5 $out/pmc.log; exit 1; }
+bash tools/pmc_passes.sh $out/pmc --steps 3 --warmup 3 --frames-in-flight 1 > $out/pmc.log 2>&1 || { tail -5 $out/pmc.log; exit 1; }
+bash tools/pmc_passes2.sh $out/pmc2 --steps 3 --warmup 3 --frames-in-flight 1 >> $out/pmc.log 2>&1 || { tail -5 $out/pmc.log; exit 1; }
 python3 tools/pmc_summary.py $out/pmc > $out/pmc_summary.txt
 python3 tools/pmc_summary.py $out/pmc2 >> $out/pmc_summary.txt
+python3 tools/pmc_traffic.py $out/pmc --no-cpu-baseline --steps 3 --warmup 3 --frames-in-flight 1 > $out/traffic_entry.json
 echo done

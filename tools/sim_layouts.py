@@ -65,15 +65,16 @@ tris8 = np.ascontiguousarray(pos[order1[ord8]].reshape(n, 9), np.float32)
 print(f"mesh {mesh_id}: {n} triangles; binary nodes {len(nodes4)} (leaf<=4) / {len(nodes1)} (leaf 1); 4-wide {c4} nodes depth {depth.value} ({c4 * 64 / 1e6:.2f} MB); "
       f"8-wide {c8} nodes depth {depth8.value} ({c8 * 80 / 1e6:.2f} MB)")
 for name, o, dd in (("surface", o_surf, d_surf), ("outside", o_out, d_out)):
-    s4 = np.zeros(3, np.uint64); s8 = np.zeros(3, np.uint64)
+    s4 = np.zeros(24, np.uint64); s8 = np.zeros(3, np.uint64)
     t4 = np.zeros(n_rays, np.float32); t8 = np.zeros(n_rays, np.float32)
     lib.pt_wide4_simulate_host(P(w4), P(tris4), n_rays, P(o), P(dd), C.c_float(1e-3), C.c_float(1e4), P(s4), P(t4), 0)
     for mode in (1, 2, 3, 5):
-        sm = np.zeros(3, np.uint64); tm = np.zeros(n_rays, np.float32)
+        sm = np.zeros(24, np.uint64); tm = np.zeros(n_rays, np.float32)
         lib.pt_wide4_simulate_host(P(w4), P(tris4), n_rays, P(o), P(dd), C.c_float(1e-3), C.c_float(1e4), P(sm), P(tm), mode)
         assert np.array_equal(tm, t4)
         print(f"    4-wide order mode {mode}: {sm[0] / n_rays:6.2f} nodes {sm[1] / n_rays:5.2f} tris (x{sm[0] / s4[0]:.3f} nodes, x{sm[1] / s4[1]:.3f} tris)")
     lib.pt_wide8_simulate_host(P(w8), P(tris8), n_rays, P(o), P(dd), C.c_float(1e-3), C.c_float(1e4), P(s8), P(t8))
     assert np.array_equal(t4, t8), (np.sum(t4 != t8))
+    print("    4-wide: share of node steps leaving >= k entries on the stack:", " ".join(f"{k}:{s4[3 + k] / s4[0]:.3f}" for k in (4, 6, 8, 10, 12, 14, 16)))
     print(f"{name:8s} hit {np.mean(t4 < 1e4):.2f} | 4-wide: {s4[0] / n_rays:6.2f} nodes {s4[1] / n_rays:5.2f} tris, stack {s4[2]} | "
           f"8-wide: {s8[0] / n_rays:6.2f} nodes {s8[1] / n_rays:5.2f} tris, stack {s8[2]} | node ratio {s8[0] / s4[0]:.3f}")
