@@ -1165,7 +1165,7 @@ int pt_tlas_build(PtContext* ctx, const PtInstance* instances, uint32_t n, PtTla
             depth_blas = uniq[k]->wide_depth > depth_blas ? uniq[k]->wide_depth : depth_blas;
         }
         // a step pushes at most three references and an instance entry one
-        if (3 * t->wide_depth + 1 + 3 * depth_blas > PT_LDS_STACK + PT_SPILL_STACK) {
+        if (3 * t->wide_depth + 1 + 3 * depth_blas > 10 + PT_SPILL_STACK) {      // the shallowest LDS part of any traversal kernel is 10 entries
             pt_set_error("pt_tlas_build: acceleration structure too deep for the traversal stack (%u + %u wide levels)", t->wide_depth, depth_blas);
             (void)hipFree(tlas_wide); return PT_ERROR_LIMIT;
         }

@@ -103,7 +103,7 @@ int pt_ctx_create(int device_id, void* hip_stream, PtContext** out)
     PtContext* c = new PtContext();
     c->device = device_id;
     c->num_cus = prop.multiProcessorCount;
-    if (const char* e = getenv("PT_HIP_TRAVERSAL")) c->traversal_mode = strcmp(e, "plain") == 0 ? 0 : (strcmp(e, "sched") == 0 ? 1 : 2);
+    if (const char* e = getenv("PT_HIP_TRAVERSAL")) c->traversal_mode = strcmp(e, "plain") == 0 ? 0 : (strcmp(e, "sched") == 0 ? 1 : (strcmp(e, "pair") == 0 ? 3 : 2));
     if (const char* e = getenv("PT_HIP_SCHED_MIN_RAYS")) c->sched_min_rays = (uint32_t)strtoul(e, nullptr, 10);
     if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
     else {

@@ -144,24 +144,29 @@ struct PtTlasView {
 typedef __attribute__((address_space(3))) int pt_lds_int;
 typedef __attribute__((address_space(3))) float pt_lds_float;
 
-struct PtStack {
-    pt_lds_int* lds;   // &s_stack[0][threadIdx.x]
+// LDS_N: entries kept in LDS.  SLICES: rays per thread that own a stack (the pair-scheduled traversal keeps
+// two rays per lane); `slice` selects the spill slice of the ray in hand.
+template <int LDS_N, int SLICES>
+struct PtStackT {
+    pt_lds_int* lds;   // &stack[0][threadIdx.x] of the ray in hand
     int* spill_base;   // spill buffer of the whole grid; this thread's slice is computed on demand
     int sp;
+    int slice;
     __device__ __forceinline__ int* spill_slot(int k) const
     {
-        return spill_base + (size_t)(blockIdx.x * PT_TRAVERSE_BLOCK + threadIdx.x) * PT_SPILL_STACK + k;
+        const size_t t = (size_t)(blockIdx.x * PT_TRAVERSE_BLOCK + threadIdx.x);
+        return spill_base + (SLICES == 1 ? t : t * SLICES + (size_t)slice) * PT_SPILL_STACK + k;
     }
     __device__ __forceinline__ void push(int v)
     {
-        if (sp < PT_LDS_STACK) lds[sp * PT_TRAVERSE_BLOCK] = v;
-        else *spill_slot(sp - PT_LDS_STACK) = v;
+        if (sp < LDS_N) lds[sp * PT_TRAVERSE_BLOCK] = v;
+        else *spill_slot(sp - LDS_N) = v;
         ++sp;
     }
     // Pushes r[m], ..., r[1] in this order (m in 0..3) so that r[1] is popped first.
     __device__ __forceinline__ void push_far_to_near(int r1, int r2, int r3, int m)
     {
-        if (sp + 3 <= PT_LDS_STACK) {
+        if (sp + 3 <= LDS_N) {
             // r[j] belongs at sp + m - j; an entry beyond m lands on slot sp first and is
             // overwritten by r[m], or stays above the new top when m == 0
             lds[(sp + max(m - 3, 0)) * PT_TRAVERSE_BLOCK] = r3;
@@ -179,19 +184,21 @@ struct PtStack {
         if (sp == 0) return PT_NODE_DONE;
         --sp;
         int v;
-        if (sp < PT_LDS_STACK) v = lds[sp * PT_TRAVERSE_BLOCK];
-        else v = *spill_slot(sp - PT_LDS_STACK);
+        if (sp < LDS_N) v = lds[sp * PT_TRAVERSE_BLOCK];
+        else v = *spill_slot(sp - LDS_N);
         return v;
     }
 };
+typedef PtStackT<PT_LDS_STACK, 1> PtStack;
 
 // One step through a 64-byte 4-wide node with child boxes quantised to 8 bits on the node's own
 // grid: (origin.xyz, step.x) (child[0..3]) (lo.x lo.y lo.z hi.x words) (hi.y hi.z words, step.y, step.z);
 // byte k of each word belongs to child k and a plane is fma(byte, step, origin).
 // Continues with the nearest child that the ray interval [tlo, hi] overlaps and pushes the others
 // so that nearer ones are popped first; returns the next item (a pop if nothing was hit).
+template <typename STACK>
 __device__ __forceinline__ int pt_wide_step(const PtRaySpace& r, const float4* __restrict__ nodes, int node,
-                                            float tlo, float hi, PtStack& stk)
+                                            float tlo, float hi, STACK& stk)
 {
     const float4 h0 = nodes[4 * (size_t)node + 0], h1 = nodes[4 * (size_t)node + 1];
     const float4 h2 = nodes[4 * (size_t)node + 2], h3 = nodes[4 * (size_t)node + 3];

@@ -137,7 +137,7 @@ struct PtContext {
     bool own_stream = false;
     int num_cus = 0;
     uint64_t max_paths = 1ull << 27;
-    int traversal_mode = 2;   // 0: one batch of 64 rays per wave at a time; 1: wave-scheduled with ray replacement; 2: chosen per level (PT_HIP_TRAVERSAL=plain|sched|auto)
+    int traversal_mode = 2;   // 0: one batch of 64 rays per wave at a time; 1: wave-scheduled with ray replacement; 2: chosen per level; 3: wave-scheduled with two rays per lane (PT_HIP_TRAVERSAL=plain|sched|auto|pair)
     uint32_t sched_min_rays = 1200000;   // mode 2: levels with at least this many rays are wave-scheduled (PT_HIP_SCHED_MIN_RAYS)
     // tables
     PtMaterial* materials = nullptr; uint32_t n_materials = 0;

@@ -25,6 +25,7 @@
 // round trip.  Survivors of shard s go to shard s of the next queue, which therefore never overflows.
 #include "pt_device.h"
 #include "pt_traverse_sched.h"
+#include "pt_traverse_pair.h"
 #include <string.h>
 #include <algorithm>
 
@@ -203,6 +204,24 @@ k_intersect(PtTlasView tl, uint32_t* __restrict__ counters, uint32_t depth, uint
             if (BY_ID && t_out) t_out[dst] = h.t;
         }
     });
+}
+
+// traceRayEXT for every ray of one bounce with two rays per lane (pt_traverse_pair.h): four waves per SIMD,
+// 40 KB of LDS per block.
+#ifndef PT_PAIR_WAVES
+#define PT_PAIR_WAVES 4
+#endif
+template <bool BY_ID>
+__global__ void __launch_bounds__(kBlock, PT_PAIR_WAVES)
+k_intersect_pair(PtTlasView tl, uint32_t* __restrict__ counters, uint32_t depth, uint32_t shard_cap,
+                 const float4* __restrict__ q0, const float4* __restrict__ q1, float tmin, float tmax,
+                 PtHit* __restrict__ hits, float* __restrict__ t_out, int* __restrict__ spill)
+{
+    __shared__ int s_pair[2 * PT_PAIR_WORDS][kBlock];
+    PtSchedQueue Q;
+    Q.counters = counters; Q.shard_cap = shard_cap; Q.n_shards = kShards; Q.ctr_pad = kCtrPad;
+    Q.count_base = ctr_index(CTR_COUNT, depth, 0); Q.work_base = ctr_index(CTR_WORK_INTERSECT, depth, 0);
+    pt_traverse_pair<BY_ID>(tl, Q, (pt_lds_int*)&s_pair[0][threadIdx.x], spill, q0, q1, tmin, tmax, hits, t_out);
 }
 
 // rays given as packed float3 arrays (pt_intersect entry point): repack into the float4 streams
@@ -729,6 +748,7 @@ uint32_t sched_threshold(const PtContext* ctx, uint32_t depth)
 {
     if (ctx->traversal_mode == 0) return 0xFFFFFFFFu;        // plain everywhere
     if (ctx->traversal_mode == 1) return 0u;                 // scheduled everywhere
+    if (ctx->traversal_mode == 3) return ctx->sched_min_rays; // (the two-rays-per-lane kernel has its own launch; this is for entry points that do not use it)
     return depth == 0 ? 0xFFFFFFFFu : ctx->sched_min_rays;   // primary rays are coherent
 }
 
@@ -798,7 +818,7 @@ extern "C" int pt_intersect_noalloc(PtContext* ctx, const PtTlas* tlas, uint32_t
     PT_HIP_CHECK(hipMemsetAsync(counters, 0, sizeof(uint32_t) * kCounterWords, st));
     k_pack_rays<<<(n + kBlock - 1) / kBlock, kBlock, 0, st>>>(n, cap, origins_dev, dirs_dev, q0, q1, counters);
     PtTlasView tv; tv.nodes = (const float4*)tlas->pool_nodes; tv.tris = tlas->pool_tris; tv.inst = tlas->inst;
-    const uint32_t thr = ctx->traversal_mode == 0 ? 0xFFFFFFFFu : (ctx->traversal_mode == 1 ? 0u : ctx->sched_min_rays);
+    const uint32_t thr = ctx->traversal_mode == 0 ? 0xFFFFFFFFu : (ctx->traversal_mode == 1 ? 0u : ctx->sched_min_rays);   // mode 3 (two rays per lane) needs twice the stack slices: not used here
     k_intersect<true><<<g_na_blocks[ctx->device], kBlock, 0, st>>>(tv, counters, 0, cap, q0, q1, tmin, tmax, hits_dev, t_dev, spill, thr);
     PT_HIP_CHECK(hipGetLastError());
     return PT_OK;
@@ -824,9 +844,15 @@ int pt_intersect(PtContext* ctx, const PtTlas* tlas, uint32_t n, const float* or
     k_pack_rays<<<(n + kBlock - 1) / kBlock, kBlock, 0, st>>>(n, w.shard_cap, origins_dev, dirs_dev, w.q[0][0], w.q[0][1], w.counters);
     {
         // caller-supplied rays are treated as incoherent: scheduled above the threshold
-        const int blocks = persistent_blocks(ctx, (const void*)k_intersect<true>);
-        k_intersect<true><<<blocks, kBlock, 0, st>>>(view_of(tlas), w.counters, 0, w.shard_cap, w.q[0][0], w.q[0][1],
-                                                     tmin, tmax, hits_dev, t_dev, w.spill, sched_threshold(ctx, 1));
+        if (ctx->traversal_mode == 3) {
+            const int blocks = std::min(persistent_blocks(ctx, (const void*)k_intersect_pair<true>), ctx->num_cus * 4);
+            k_intersect_pair<true><<<blocks, kBlock, 0, st>>>(view_of(tlas), w.counters, 0, w.shard_cap, w.q[0][0], w.q[0][1],
+                                                              tmin, tmax, hits_dev, t_dev, w.spill);
+        } else {
+            const int blocks = persistent_blocks(ctx, (const void*)k_intersect<true>);
+            k_intersect<true><<<blocks, kBlock, 0, st>>>(view_of(tlas), w.counters, 0, w.shard_cap, w.q[0][0], w.q[0][1],
+                                                         tmin, tmax, hits_dev, t_dev, w.spill, sched_threshold(ctx, 1));
+        }
     }
     PT_HIP_CHECK(hipGetLastError());
     return pt_lanes_join(ctx);   // the hit records are ordered on the caller's stream
@@ -855,6 +881,7 @@ int pt_trace(PtContext* ctx, const PtTlas* tlas, const float camera[32], uint32_
     memcpy(primary.camera.m, camera, sizeof primary.camera.m);
     primary.spp = spp; primary.W = width; primary.H = height; primary.frame = frame; primary.seed_mode = seed_mode;
     const int blocks_i = persistent_blocks(ctx, (const void*)k_intersect<false>);
+    const int blocks_pair = std::min(persistent_blocks(ctx, (const void*)k_intersect_pair<false>), ctx->num_cus * 4);   // two stack slices per thread
     // whole multiples of kShards waves (four waves per block): the passes that deal batches by index need them
     const int blocks_p = std::max(16, persistent_blocks(ctx, (const void*)k_primary) / 16 * 16);
     const int blocks_s = std::max(16, persistent_blocks(ctx, (const void*)k_shade) * PT_SHADE_GRID / 16 * 16);
@@ -896,8 +923,12 @@ int pt_trace(PtContext* ctx, const PtTlas* tlas, const float camera[32], uint32_
                 k_primary<<<blocks_p, kBlock, 0, st>>>(tv, sa, 0.001f, 10000.0f, w.spill);
                 if (ev_stop) PT_HIP_CHECK(hipEventRecord(ev_stop, st));
             } else {
-                k_intersect<false><<<blocks_i, kBlock, 0, st>>>(tv, w.counters, d, w.shard_cap, w.q[a][0], w.q[a][1],
-                                                                0.001f, 10000.0f, w.hits, nullptr, w.spill, sched_threshold(ctx, d));
+                if (ctx->traversal_mode == 3)
+                    k_intersect_pair<false><<<blocks_pair, kBlock, 0, st>>>(tv, w.counters, d, w.shard_cap, w.q[a][0], w.q[a][1],
+                                                                            0.001f, 10000.0f, w.hits, nullptr, w.spill);
+                else
+                    k_intersect<false><<<blocks_i, kBlock, 0, st>>>(tv, w.counters, d, w.shard_cap, w.q[a][0], w.q[a][1],
+                                                                    0.001f, 10000.0f, w.hits, nullptr, w.spill, sched_threshold(ctx, d));
                 if (ev_stop) PT_HIP_CHECK(hipEventRecord(ev_stop, st));
                 k_shade<<<blocks_s, kBlock, 0, st>>>(sa, w.hits);
             }

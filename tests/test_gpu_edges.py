@@ -46,7 +46,7 @@ def _compare(scene, o, d, schedule, monkeypatch):
         r.close()
 
 
-@pytest.mark.parametrize("schedule", ["plain", "sched"])
+@pytest.mark.parametrize("schedule", ["plain", "sched", "pair"])
 def test_degenerate_rays(cube, schedule, monkeypatch):
     """Zero direction components (the slab reciprocal is clamped), a zero direction, rays through
     vertices and along edges, origins on faces and inside, and directions of tiny or huge length."""
@@ -77,7 +77,7 @@ def test_degenerate_rays(cube, schedule, monkeypatch):
     assert (ho["instance"] != 0xFFFFFFFF).sum() > 500
 
 
-@pytest.mark.parametrize("schedule", ["plain", "sched"])
+@pytest.mark.parametrize("schedule", ["plain", "sched", "pair"])
 def test_single_triangle_and_degenerate_triangles(schedule, monkeypatch):
     """A one-triangle BLAS (no inner node), then a mesh mixing proper, zero-area and repeated
     triangles (all keys equal, ties in the radix tree), instanced three times with scale and shear."""

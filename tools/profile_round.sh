@@ -30,6 +30,13 @@ if [ -z "${SKIP_CONFIGS:-}" ]; then
     prof cfg_$c python3 bench.py --scene $c $extra --steps 3 --warmup 1 --frames-in-flight 1 --no-cpu-baseline --no-secondary
   done
 fi
+# lane utilisation of the scheduled traversals (needs variants/stats.so: tools/build_variant.sh stats -DPT_SCHED_STATS)
+if [ -f variants/stats.so ]; then
+  for mode in auto pair; do
+    SPP=64 PT_HIP_LIB=variants/stats.so PT_HIP_TRAVERSAL=$mode timeout -k 10 200 python3 tools/sched_stats.py > $out/sched_stats_$mode.txt 2>&1
+  done
+  bash tools/ab_env.sh "auto:PT_X=0" "pair:PT_HIP_TRAVERSAL=pair" "sched:PT_HIP_TRAVERSAL=sched" "plain:PT_HIP_TRAVERSAL=plain" > $out/schedules_ab.txt 2>&1
+fi
 [ -n "${SKIP_PMC:-}" ] && { echo done; exit 0; }
 bash tools/pmc_passes.sh $out/pmc --steps 3 --warmup 3 --frames-in-flight 1 > $out/pmc.log 2>&1 || { tail -5 $out/pmc.log; exit 1; }
 bash tools/pmc_passes2.sh $out/pmc2 --steps 3 --warmup 3 --frames-in-flight 1 >> $out/pmc.log 2>&1 || { tail -5 $out/pmc.log; exit 1; }

@@ -16,7 +16,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "cornell":
     scene = Scene.load_npz(os.path.join(ROOT, "tests", "golden", "scene_cornell.npz"))
 else:
     scene = procedural.dragon_standin()
-W, H, SPP = 1920, 1080, 4
+W, H, SPP = 1920, 1080, int(os.environ.get("SPP", "4"))
 r = hip.Renderer(scene, W, H)
 lib = r.ctx.lib
 out = (C.c_ulonglong * 8)()
