@@ -206,6 +206,12 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    trace_t0 = time.perf_counter()
+
+    def phase(what):          # PT_BENCH_TRACE=1: where the wall-clock goes, per rank, on stderr
+        if os.environ.get("PT_BENCH_TRACE") == "1":
+            print(f"[bench rank {rank}] {time.perf_counter() - trace_t0:8.3f} s  {what}", file=sys.stderr, flush=True)
+
     W, H = args.width, args.height
     scene = build_scene(args.scene)
     cam = scene_camera(args.scene, W, H)
@@ -219,6 +225,7 @@ def main():
     r = hip.Renderer(scene, W, H, device=local_rank, stream=stream, camera=cam)
     torch.cuda.synchronize()
     setup_s = time.perf_counter() - t0
+    phase("renderer built")
     build_ms = sum(float(b.info()["build_ms"]) for b in r.blases) + float(r.tlas.info()["build_ms"])
     accum = torch.zeros(H * W * 4, dtype=torch.float32, device="cuda")
     torch.cuda.synchronize()
@@ -244,6 +251,7 @@ def main():
                 raise
             print(f"bench.py: {args.spp} spp per step does not fit ({e}); halving the step", file=sys.stderr)
             args.spp //= 2
+    phase(f"first step done ({args.spp} spp)")
     fif_choice = None
     if args.frames_in_flight == 0:
         # one or two steps in flight, by measurement: two cost a second set of queues and must earn it
@@ -275,6 +283,7 @@ def main():
         dist.all_reduce(t_spp, op=dist.ReduceOp.MIN)
         args.spp = int(t_spp[0])
         set_chunk()
+    phase(f"step agreed: {args.spp} spp, {fif} in flight")
     strong = args.total_spp > 0
     if strong:
         total_steps = max(1, -(-args.total_spp // args.spp))
@@ -294,7 +303,9 @@ def main():
     # that every internal stream has allocated its path queues before the clock starts
     run_frames(r, accum.data_ptr(), my_frames(max(args.warmup, fif), 1_000_000), args.spp, args.max_depth)
     r.ctx.sync()                    # frames in flight still add to the image
+    phase("warm-up steps done")
     sharding.allreduce_sum(accum)   # the collective's first call sets up its communicator and buffers: not timed
+    phase("warm-up all-reduce done")
     accum.zero_()
     r.reset_stats()
     # The traversal launches are bracketed by HIP events on the streams they run on: during the timed steps when
@@ -306,13 +317,19 @@ def main():
     barrier()
     t0 = time.perf_counter()
     run_frames(r, accum.data_ptr(), my_timed, args.spp, args.max_depth)
-    r.fence()                       # the context's stream (torch's current one) waits for every frame in flight
+    phase("timed steps enqueued")
+    # The host waits for the frames in flight before the collective is issued (some 20 us on a step of 120 ms).
+    # A stream-side wait (r.fence()) would do for RCCL, but the gloo rehearsal, whose all-reduce stages through
+    # pinned host memory from a thread of its own, then crawled with two ranks on one GPU: launches of 10 s and more.
+    r.ctx.sync()
+    phase("timed steps done")
     ar0, ar1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ar0.record()
     sharding.allreduce_sum(accum)
     ar1.record()
     barrier()
     elapsed = time.perf_counter() - t0
+    phase("timed region closed")
     allreduce_ms = ar0.elapsed_time(ar1) if world > 1 else 0.0
     prof = r.profile()
     st = r.stats()
