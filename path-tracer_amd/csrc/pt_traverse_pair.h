@@ -225,7 +225,7 @@ __device__ __forceinline__ void pt_traverse_pair(const PtTlasView& tl, const PtS
                     if ((unsigned)next < (unsigned)PT_NODE_DONE) A.node = next; else advance(next);
                     A.sp = stk.sp;
                 }
-                n_node = __popcll(__ballot(want_node(A) | want_node(B)));
+                n_node = __popcll(__ballot(want_node(A) || want_node(B)));
             } while (--steps > 0 && n_node >= PT_PAIR_NODE_STAY);
         } else if (phase == 1) {
             int steps = PT_PAIR_LEAF_STEPS;
@@ -259,7 +259,7 @@ __device__ __forceinline__ void pt_traverse_pair(const PtTlasView& tl, const PtS
                     if (code & 7u) A.node = (int)~(code + 7u);
                     else { stk.sp = A.sp; advance(stk.pop()); A.sp = stk.sp; }
                 }
-                n_leaf = __popcll(__ballot(want_leaf(A) | want_leaf(B)));
+                n_leaf = __popcll(__ballot(want_leaf(A) || want_leaf(B)));
             } while (--steps > 0 && n_leaf >= PT_PAIR_LEAF_VOTES / 2);
         } else {
             swap_if(!want_enter(A) && want_enter(B));

@@ -104,19 +104,11 @@ __device__ __forceinline__ void pt_traverse_sched(const PtTlasView& tl, const Pt
     // Takes the next item for this lane after the current one is exhausted: pops until an inner node,
     // a leaf, the end of an instance's BLAS (with something left above it) or the end of the ray comes up.
     auto advance = [&](int v) {
-        for (;;) {
-            if (v == PT_NODE_SENTINEL) {
-                // nothing left above the instance: the ray is finished, its world-space form is not needed
-                if (stk.sp == 0) { v = PT_NODE_DONE; continue; }
-                // a few lanes at a time get here and the whole wave pays for what they do: the lane waits
-                // for the instance phase, which takes it back to world space together with the lanes that
-                // enter or leave an instance then
-                node = v;
-                return;
-            }
-            node = v;
-            return;
-        }
+        // Leaving an instance with nothing left above it: the ray is finished, its world-space form is not
+        // needed.  Otherwise the sentinel stays the lane's item: a few lanes at a time get here and the whole
+        // wave would pay for what they do, so the lane waits for the instance phase, which takes it back to
+        // world space together with the lanes that enter or leave an instance then.
+        node = (v == PT_NODE_SENTINEL && stk.sp == 0) ? PT_NODE_DONE : v;
     };
 
     // A finished ray keeps its closest hit in `cold` until its lane is refilled (or the wave ends): rays
@@ -140,6 +132,7 @@ __device__ __forceinline__ void pt_traverse_sched(const PtTlasView& tl, const Pt
         if (idle == ~0ull || __popcll(idle) >= PT_SCHED_REFILL) flush();
         if (!drained && (idle == ~0ull || __popcll(idle) >= PT_SCHED_REFILL)) {
             while (idle) {
+                PT_STAT(7, 1);
                 if (wcur == wend) {
                     bool got = false;
                     while (avail) {

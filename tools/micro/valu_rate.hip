@@ -84,6 +84,16 @@ __global__ void __launch_bounds__(256) k_rate(float* out, float a, float b, uint
             if (KIND == 37) asm volatile("v_cvt_f32_ubyte0 %0, %1" : "=v"(x[i]) : "v"(word));
             if (KIND == 38) asm volatile("v_lshlrev_b32 %0, 3, %0" : "+v"(x[i]) : );
             if (KIND == 39) asm volatile("v_cmp_class_f32 vcc, %0, %1" : : "v"(x[i]), "v"(a) : "vcc");
+            if (KIND == 60) asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(x[i]) : "v"(word), "v"(a));
+            if (KIND == 61) asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(x[i]) : "v"(word), "v"(a));
+            if (KIND == 62) asm volatile("v_cvt_f32_f16 %0, %1" : "=v"(x[i]) : "v"(word));
+            if (KIND == 63) asm volatile("v_pk_fma_f16 %0, %0, %1, %1" : "+v"(x[i]) : "v"(a));
+            if (KIND == 64) asm volatile("v_pk_max_f16 %0, %0, %1" : "+v"(x[i]) : "v"(a));
+            if (KIND == 65) asm volatile("v_pk_add_f16 %0, %0, %1" : "+v"(x[i]) : "v"(a));
+            if (KIND == 66) asm volatile("v_cvt_f32_ubyte0_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2" : "=v"(x[i]) : "v"(word));
+            if (KIND == 67) asm volatile("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]\n v_fma_f32 %0, %0, %2, %3" : "=v"(x[i]) : "v"(word), "v"(a), "v"(b));
+            if (KIND == 68) asm volatile("v_cvt_f32_ubyte1 %0, %1\n v_fma_f32 %0, %0, %2, %3\n v_fma_f32 %0, %0, %2, %3" : "=v"(x[i]) : "v"(word), "v"(a), "v"(b));
+            if (KIND == 69) asm volatile("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(x[i]) : "v"(word), "v"(a), "v"(b));
         }
     }
     const unsigned long long c1 = clock64();
@@ -120,11 +130,26 @@ int run(const char* name, int cus)
     return 0;
 }
 
-int main()
+int main(int argc, char** argv)
 {
     hipDeviceProp_t p; CHECK(hipGetDeviceProperties(&p, 0));
     const int cus = p.multiProcessorCount;
     printf("%s, %d CUs\n", p.gcnArchName, cus);
+    if (argc > 1 && argv[1][0] == 'm') {       // the mixed-precision and 16-bit forms only
+        if (run<0>("v_fma_f32", cus)) return 1;
+        if (run<2>("v_cvt_f32_ubyte1", cus)) return 1;
+        if (run<60>("v_fma_mix_f32 lo", cus)) return 1;
+        if (run<61>("v_fma_mix_f32 hi", cus)) return 1;
+        if (run<69>("v_fma_mix_f32 indep", cus)) return 1;
+        if (run<62>("v_cvt_f32_f16", cus)) return 1;
+        if (run<63>("v_pk_fma_f16", cus)) return 1;
+        if (run<64>("v_pk_max_f16", cus)) return 1;
+        if (run<65>("v_pk_add_f16", cus)) return 1;
+        if (run<66>("v_cvt_f32_ubyte sdwa", cus)) return 1;
+        if (run<67>("mix+fma (x2 instr)", cus)) return 1;
+        if (run<68>("cvt+fma+fma (x3 instr)", cus)) return 1;
+        return 0;
+    }
     if (run<50>("e32cnd+3add (x4 instr)", cus)) return 1;
     if (run<51>("e64cnd+3add (x4 instr)", cus)) return 1;
     if (run<52>("cmp+e32cnd (x2 instr)", cus)) return 1;

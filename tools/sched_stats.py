@@ -25,11 +25,12 @@ r.render(spp=SPP, max_depth=10, frame=0)
 r.ctx.sync() if hasattr(r.ctx, "sync") else None
 print("rc", lib.pt_debug_sched_stats(out, 1), lib.pt_last_error())
 st = r.stats()
-rays = int(st["rays"])
+# bounce 0 runs in k_primary (plain schedule, not counted): the phases below serve the later bounces' rays only
+rays = int(st["rays"]) - int(st["rays_per_depth"][0])
 v = [int(x) for x in out]
-print("rays", rays)
+print("rays of bounces 1+", rays, "of", int(st["rays"]))
 for k, name in enumerate(("node", "triangle", "enter")):
     it, act = v[k], v[3 + k]
     print(f"{name:9s} wave iterations {it:12d}  per 64 rays {it / (rays / 64):8.2f}  lanes active {act / max(it, 1):6.2f}  lane-steps per ray {act / rays:7.2f}")
-print("outer iterations per 64 rays", v[6] / (rays / 64))
+print("outer iterations per 64 rays", v[6] / (rays / 64), " refill rounds per 64 rays", v[7] / (rays / 64))
 r.close()
