@@ -39,16 +39,16 @@
 #define PT_SCHED_LEAF_VOTES 20     // run the triangle phase once this many lanes wait in it ...
 #endif
 #ifndef PT_SCHED_ENTER_VOTES
-#define PT_SCHED_ENTER_VOTES 10    // ... the instance-entry phase at this many ...
+#define PT_SCHED_ENTER_VOTES 16    // ... the instance-entry phase at this many ...
 #endif
 #ifndef PT_SCHED_NODE_MIN
 #define PT_SCHED_NODE_MIN 24       // ... or when fewer than this many lanes want a box step
 #endif
 #ifndef PT_SCHED_NODE_STEPS
-#define PT_SCHED_NODE_STEPS 6      // box steps per vote while at least half the wave takes part
+#define PT_SCHED_NODE_STEPS 10     // box steps per vote while enough lanes take part
 #endif
 #ifndef PT_SCHED_NODE_STAY
-#define PT_SCHED_NODE_STAY 32      // ... and only while this many lanes still take part
+#define PT_SCHED_NODE_STAY 24      // ... that is, while this many lanes still do
 #endif
 #ifndef PT_SCHED_LEAF_STEPS
 #define PT_SCHED_LEAF_STEPS 4      // triangles per vote while enough lanes take part
