@@ -144,9 +144,13 @@ int pt_buffer_free(PtContext* ctx, void* dev);
 int pt_blas_build(PtContext* ctx, const void* vertices_dev, uint32_t vertex_stride, uint32_t max_vertex,
                   const uint32_t* indices_dev, uint32_t prim_count, uint32_t max_leaf, PtBlas** out);
 int pt_blas_destroy(PtBlas* blas);   /* destroyAccelerationStructureKHR, bottom_level_...cpp:19 */
+/* node_count is that of the Morton-order tree below: 0 until that tree exists. */
 int pt_blas_info(const PtBlas* blas, PtAsInfo* out);
-/* Copies the built structure to the host (any pointer may be NULL): nodes[node_count],
- * leaf_prims[prim_count] (primitive ids in sorted order), sorted_keys[prim_count]. */
+/* Copies the Morton-order binary tree to the host (any pointer may be NULL): nodes[node_count],
+ * leaf_prims[prim_count] (primitive ids in sorted order), sorted_keys[prim_count].  The kernels traverse
+ * the binned-SAH tree (pt_blas_traversal_download), so the Morton tree is built by the first call of this
+ * function, from the vertex and index buffers given to pt_blas_build; call it with three NULLs to have
+ * the tree built and pt_blas_info report its node_count. */
 int pt_blas_download(const PtBlas* blas, PtBvhNode* nodes, uint32_t* leaf_prims, uint64_t* sorted_keys);
 /* The layout the kernels traverse, derived on the GPU from a binary tree (pt_blas_traversal_download
  * below; for a TLAS its Morton tree): 64-byte nodes

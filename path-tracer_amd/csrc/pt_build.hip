@@ -15,6 +15,7 @@
 #include <math.h>
 #include <string.h>
 #include <algorithm>
+#include <chrono>
 #include <limits>
 
 namespace {
@@ -57,19 +58,21 @@ __global__ void k_tri_boxes(const uint8_t* __restrict__ vertices, uint32_t strid
                             uint32_t n_prims, const uint32_t* __restrict__ maxabs_bits, float* __restrict__ boxes,
                             uint32_t* __restrict__ root_ord /* 6: lo xyz (min), hi xyz (max) */)
 {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_prims) return;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = i < n_prims;
+    const uint32_t j = valid ? i : n_prims - 1;          // lanes past the end repeat the last primitive: min and max do not mind
     const float delta = __uint_as_float(*maxabs_bits) * 3.0517578125e-05f;
-    const float* a = (const float*)(vertices + (size_t)indices[3 * i + 0] * stride);
-    const float* b = (const float*)(vertices + (size_t)indices[3 * i + 1] * stride);
-    const float* c = (const float*)(vertices + (size_t)indices[3 * i + 2] * stride);
+    const float* a = (const float*)(vertices + (size_t)indices[3 * j + 0] * stride);
+    const float* b = (const float*)(vertices + (size_t)indices[3 * j + 1] * stride);
+    const float* c = (const float*)(vertices + (size_t)indices[3 * j + 2] * stride);
     for (int k = 0; k < 3; ++k) {
         float lo = fminf(fminf(a[k], b[k]), c[k]) - delta;
         float hi = fmaxf(fmaxf(a[k], b[k]), c[k]) + delta;
-        boxes[6 * (size_t)i + k] = lo;
-        boxes[6 * (size_t)i + 3 + k] = hi;
-        atomicMin(&root_ord[k], f2ord(lo));
-        atomicMax(&root_ord[3 + k], f2ord(hi));
+        if (valid) { boxes[6 * (size_t)i + k] = lo; boxes[6 * (size_t)i + 3 + k] = hi; }
+        // one pair of atomics per wave instead of per primitive
+        uint32_t ul = f2ord(lo), uh = f2ord(hi);
+        for (int off = 32; off > 0; off >>= 1) { ul = min(ul, (uint32_t)__shfl_xor(ul, off)); uh = max(uh, (uint32_t)__shfl_xor(uh, off)); }
+        if ((threadIdx.x & 63) == 0) { atomicMin(&root_ord[k], ul); atomicMax(&root_ord[3 + k], uh); }
     }
 }
 
@@ -218,12 +221,35 @@ __global__ void k_scan_sums(uint32_t* __restrict__ sums, uint32_t n_blocks, uint
         if (threadIdx.x == kBlock - 1) carry = x + add;
         __syncthreads();
     }
-    if (threadIdx.x == 0 && total) *total = carry;
+    if (threadIdx.x == 0 && total) __hip_atomic_store(total, carry, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 __global__ void k_scan_add(uint32_t* __restrict__ out, uint32_t n, const uint32_t* __restrict__ block_sums)
 {
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i < n) out[i] += block_sums[blockIdx.x];
+}
+// The same with the block sums as k_scan_block left them: every block adds up the sums in front of it
+// (a few hundred words for the arrays of a build), which saves the launch in between.
+__global__ void k_scan_add_raw(uint32_t* __restrict__ out, uint32_t n, const uint32_t* __restrict__ block_sums, uint32_t n_blocks,
+                               uint32_t* __restrict__ total)
+{
+    __shared__ uint32_t wsum[4];
+    const bool last = blockIdx.x == n_blocks - 1;
+    const uint32_t upto = (last && total) ? n_blocks : blockIdx.x;      // the last block also reports the grand total
+    uint32_t mine = 0, own = 0;
+    for (uint32_t k = threadIdx.x; k < upto; k += kBlock) { const uint32_t v = block_sums[k]; if (k < blockIdx.x) mine += v; else own += v; }
+    for (int off = 32; off > 0; off >>= 1) { mine += __shfl_xor(mine, off); own += __shfl_xor(own, off); }
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    const uint32_t add = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) out[i] += add;
+    if (last && total) {
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = own;
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(total, add + wsum[0] + wsum[1] + wsum[2] + wsum[3], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // ---------------------------------------------------------------- Karras 2012 radix tree
@@ -500,7 +526,7 @@ k_sah_bins(uint32_t n, const uint32_t* __restrict__ ids, const float* __restrict
 // (pt_sah_finish) lane 0 then runs on the winner.
 __global__ void __launch_bounds__(64)
 k_sah_decide(uint32_t t_lo, uint32_t t_hi, PtSahTask* __restrict__ tasks,
-             const SahBinsOrd* __restrict__ bins, uint32_t max_leaf, const float* __restrict__ boxes,
+             SahBinsOrd* __restrict__ bins, uint32_t max_leaf, const float* __restrict__ boxes,
              const uint32_t* __restrict__ ids, uint32_t* __restrict__ inner)
 {
     const uint32_t t = t_lo + blockIdx.x;
@@ -508,7 +534,7 @@ k_sah_decide(uint32_t t_lo, uint32_t t_hi, PtSahTask* __restrict__ tasks,
     const uint32_t lane = threadIdx.x;
     const int ax = (int)(lane >> 4), q = (int)(lane & 15u);
     const bool bin_lane = lane < 48u;
-    const SahBinsOrd& O = bins[t - t_lo];
+    SahBinsOrd& O = bins[t - t_lo];
     const float inf = __builtin_inff();
     const PtSahTask* T = &tasks[t];
     float c6[6];
@@ -520,6 +546,9 @@ k_sah_decide(uint32_t t_lo, uint32_t t_hi, PtSahTask* __restrict__ tasks,
     if (bin_lane) {
         cnt = O.cnt[ax][q];
         if (cnt) for (int k = 0; k < 3; ++k) { lo[k] = ord2f(O.lo[ax][q][k]); hi[k] = ord2f(O.hi[ax][q][k]); }
+        // the bins go back to the identities for the range that uses them next (k_sah_reset runs once per build)
+        O.cnt[ax][q] = 0u;
+        for (int k = 0; k < 3; ++k) { O.lo[ax][q][k] = 0xFFFFFFFFu; O.hi[ax][q][k] = 0u; }
     }
     // inclusive prefix (bins 0..q) and suffix (bins q..15) along the axis
     uint32_t pn = cnt, sn = cnt;
@@ -561,36 +590,34 @@ k_sah_decide(uint32_t t_lo, uint32_t t_hi, PtSahTask* __restrict__ tasks,
     inner[t] = task.kind != 0 ? 1u : 0u;
 }
 
-// Numbers the inner ranges of the level (offsets = exclusive scan of `inner`), writes their nodes and
-// the reference each range's parent holds.
-__global__ void k_sah_emit(uint32_t m, PtSahTask* __restrict__ tasks, const uint32_t* __restrict__ offsets, uint32_t node_base,
-                           PtBvhNode* __restrict__ nodes)
-{
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= m) return;
-    PtSahTask& task = tasks[t];
-    int32_t ref;
-    if (task.kind == 0) ref = pt_sah_leaf_ref(task.a, task.b - task.a);
-    else {
-        const uint32_t idx = node_base + offsets[t];
-        task.node = idx;
-        PtBvhNode& nd = nodes[idx];
-        for (int k = 0; k < 3; ++k) { nd.lo0[k] = task.lo0[k]; nd.hi0[k] = task.hi0[k]; nd.lo1[k] = task.lo1[k]; nd.hi1[k] = task.hi1[k]; }
-        nd.aux0 = nd.aux1 = 0;
-        ref = (int32_t)idx;
-    }
-    if (task.parent >= 0) { if (task.side) nodes[task.parent].c1 = ref; else nodes[task.parent].c0 = ref; }
-}
-
-__global__ void k_sah_flags(uint32_t n, const uint32_t* __restrict__ ids, const float* __restrict__ boxes,
-                            const uint32_t* __restrict__ task_of, const PtSahTask* __restrict__ tasks, uint32_t* __restrict__ flags)
+// The side of its range's split every primitive goes to.  Thread t < m also numbers range t if it is an inner one
+// (offsets = exclusive scan of `inner`), writes its node and the reference its parent holds; that touches the
+// range's `node` field only, which nothing else here reads.
+__global__ void k_sah_emit_flags(uint32_t n, const uint32_t* __restrict__ ids, const float* __restrict__ boxes,
+                                 const uint32_t* __restrict__ task_of, PtSahTask* __restrict__ tasks, uint32_t* __restrict__ flags,
+                                 uint32_t m, const uint32_t* __restrict__ offsets, uint32_t node_base, PtBvhNode* __restrict__ nodes)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t t = task_of[i];
-    uint32_t f = 0;
-    if (t != PT_SAH_NONE && tasks[t].kind != 0) f = pt_sah_goes_left(tasks[t], boxes + 6 * (size_t)ids[i], i) ? 1u : 0u;
-    flags[i] = f;
+    if (i < n) {
+        const uint32_t t = task_of[i];
+        uint32_t f = 0;
+        if (t != PT_SAH_NONE && tasks[t].kind != 0) f = pt_sah_goes_left(tasks[t], boxes + 6 * (size_t)ids[i], i) ? 1u : 0u;
+        flags[i] = f;
+    }
+    if (i < m) {
+        PtSahTask& task = tasks[i];
+        int32_t ref;
+        if (task.kind == 0) ref = pt_sah_leaf_ref(task.a, task.b - task.a);
+        else {
+            const uint32_t idx = node_base + offsets[i];
+            task.node = idx;
+            PtBvhNode& nd = nodes[idx];
+            for (int k = 0; k < 3; ++k) { nd.lo0[k] = task.lo0[k]; nd.hi0[k] = task.hi0[k]; nd.lo1[k] = task.lo1[k]; nd.hi1[k] = task.hi1[k]; }
+            nd.aux0 = nd.aux1 = 0;
+            ref = (int32_t)idx;
+        }
+        if (task.parent >= 0) { if (task.side) nodes[task.parent].c1 = ref; else nodes[task.parent].c0 = ref; }
+    }
 }
 
 // Stable partition of every split range (left[] = exclusive scan of flags over all positions) and the
@@ -687,13 +714,49 @@ hipError_t read_word(PtContext* ctx, const uint32_t* dev, uint32_t* out)
     return e;
 }
 
+// A per-level total without a stream synchronisation: the scan's last kernel stores it into a mapped host word
+// that the host has set to an impossible value beforehand and then polls (a few microseconds after the store
+// instead of a copy and a wait for the stream; the builders do this once per tree level).  Totals are counts of
+// nodes or primitives, below 2^31.
+constexpr uint32_t kMailboxEmpty = 0xFFFFFFFFu;
+hipError_t mailbox_arm(PtContext* ctx, int slot, uint32_t** dev_word)
+{
+    if (!ctx->mailbox) {
+        hipError_t e = hipHostMalloc((void**)&ctx->mailbox, 256, hipHostMallocMapped | hipHostMallocCoherent);
+        if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&ctx->mailbox_dev, ctx->mailbox, 0);
+        if (e != hipSuccess) { if (ctx->mailbox) (void)hipHostFree(ctx->mailbox); ctx->mailbox = nullptr; return e; }
+    }
+    __atomic_store_n(&ctx->mailbox[slot], kMailboxEmpty, __ATOMIC_RELEASE);
+    *dev_word = ctx->mailbox_dev + slot;
+    return hipSuccess;
+}
+hipError_t mailbox_wait(PtContext* ctx, int slot, uint32_t* out)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spin = 0;; ++spin) {
+        const uint32_t v = __atomic_load_n(&ctx->mailbox[slot], __ATOMIC_ACQUIRE);
+        if (v != kMailboxEmpty) { *out = v; return hipSuccess; }
+        if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;
+    }
+    // not seen in time (a stalled queue, or a failed launch): wait for the stream and look once more
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return e;
+    const uint32_t v = __atomic_load_n(&ctx->mailbox[slot], __ATOMIC_ACQUIRE);
+    if (v == kMailboxEmpty) return hipErrorUnknown;
+    *out = v;
+    return hipSuccess;
+}
+
 int scan_exclusive(hipStream_t st, DevMem& mem, const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* total_dev, uint32_t* sums = nullptr)
 {
     uint32_t nb = div_up(n, kBlock);
     if (!sums) PT_HIP_CHECK(mem.alloc(&sums, nb));   // callers in a loop pass their own div_up(n, 256) words
     k_scan_block<<<nb, kBlock, 0, st>>>(in, out, n, sums);
-    k_scan_sums<<<1, kBlock, 0, st>>>(sums, nb, total_dev);
-    k_scan_add<<<nb, kBlock, 0, st>>>(out, n, sums);
+    if (nb <= 4096) k_scan_add_raw<<<nb, kBlock, 0, st>>>(out, n, sums, nb, total_dev);
+    else {
+        k_scan_sums<<<1, kBlock, 0, st>>>(sums, nb, total_dev);
+        k_scan_add<<<nb, kBlock, 0, st>>>(out, n, sums);
+    }
     PT_HIP_CHECK(hipGetLastError());
     return PT_OK;
 }
@@ -722,7 +785,7 @@ int radix_sort_pairs(hipStream_t st, DevMem& mem, uint64_t** keys, uint32_t** va
 } // namespace
 
 // Binned-SAH binary tree over the padded primitive boxes (n > 1).  nodes_out[0] is the root;
-// order_out[p] = primitive at leaf position p.
+// order_out[p] = primitive at leaf position p.  Both arrive pointing at the caller's buffers (n nodes, n words).
 int pt_build_sah(PtContext* ctx, const float* boxes, uint32_t n, uint32_t max_leaf, const uint32_t* root_ord,
                  PtBvhNode** nodes_out, uint32_t* node_count_out, uint32_t** order_out)
 {
@@ -730,37 +793,44 @@ int pt_build_sah(PtContext* ctx, const float* boxes, uint32_t n, uint32_t max_le
     DevMem mem(ctx);
     const uint32_t kBatch = 32768;                      // ranges whose bins are resident at once (44 MB)
     uint32_t *ids_a = nullptr, *ids_b = nullptr, *tof_a = nullptr, *tof_b = nullptr, *flags = nullptr, *left = nullptr;
-    uint32_t *inner = nullptr, *offsets = nullptr, *total = nullptr;
-    PtSahTask *tasks_a = nullptr, *tasks_b = nullptr; SahBinsOrd* bins = nullptr; PtBvhNode* nodes = nullptr; uint32_t* sums = nullptr;
+    uint32_t *inner = nullptr, *offsets = nullptr;
+    PtSahTask *tasks_a = nullptr, *tasks_b = nullptr; SahBinsOrd* bins = nullptr; PtBvhNode* nodes = *nodes_out; uint32_t* sums = nullptr;
+    PT_REQUIRE(nodes && *order_out, "pt_build_sah: output buffers missing");
     hipError_t e = hipSuccess;
-    if ((e = mem.alloc_own(&ids_a, n)) || (e = mem.alloc_own(&ids_b, n)) || (e = mem.alloc(&tof_a, n)) || (e = mem.alloc(&tof_b, n)) ||
+    if ((e = mem.alloc(&ids_a, n)) || (e = mem.alloc(&ids_b, n)) || (e = mem.alloc(&tof_a, n)) || (e = mem.alloc(&tof_b, n)) ||
         (e = mem.alloc(&flags, n)) || (e = mem.alloc(&left, n)) || (e = mem.alloc(&inner, n)) || (e = mem.alloc(&offsets, n)) ||
-        (e = mem.alloc(&total, 4)) || (e = mem.alloc(&tasks_a, n)) || (e = mem.alloc(&tasks_b, n)) ||
-        (e = mem.alloc(&bins, kBatch)) || (e = mem.alloc_own(&nodes, n)) || (e = mem.alloc(&sums, div_up(n, kBlock) + 1))) {
+        (e = mem.alloc(&tasks_a, n)) || (e = mem.alloc(&tasks_b, n)) ||
+        (e = mem.alloc(&bins, kBatch)) || (e = mem.alloc(&sums, div_up(n, kBlock) + 1))) {
         pt_set_error("pt_build_sah: hipMalloc failed: %s", hipGetErrorString(e)); return PT_ERROR_OUT_OF_MEMORY;
     }
     const uint32_t nb = div_up(n, kBlock);
     k_iota<<<nb, kBlock, 0, st>>>(ids_a, n);
     PT_HIP_CHECK(hipMemsetAsync(tof_a, 0, sizeof(uint32_t) * n, st));          // every primitive in range 0
     k_sah_root<<<1, 1, 0, st>>>(root_ord, n, tasks_a);
+    {   // identities in every bin once; k_sah_decide restores them after reading
+        const uint32_t mb = n < kBatch ? n : kBatch;
+        k_sah_reset<<<div_up(mb * (uint32_t)(sizeof(SahBinsOrd) / 4), kBlock), kBlock, 0, st>>>(mb, bins);
+    }
     uint32_t m = 1, node_base = 0, levels = 0;
     while (m) {
         if (++levels > 4096 || m > n || node_base >= n) { pt_set_error("pt_build_sah: did not converge"); return PT_ERROR_HIP; }
         for (uint32_t t_lo = 0; t_lo < m; t_lo += kBatch) {
             const uint32_t t_hi = t_lo + kBatch < m ? t_lo + kBatch : m, mb = t_hi - t_lo;
-            k_sah_reset<<<div_up(mb * (uint32_t)(sizeof(SahBinsOrd) / 4), kBlock), kBlock, 0, st>>>(mb, bins);
             k_sah_bins<<<nb, kBlock, 0, st>>>(n, ids_a, boxes, tof_a, t_lo, t_hi, tasks_a, bins);
             k_sah_decide<<<mb, 64, 0, st>>>(t_lo, t_hi, tasks_a, bins, max_leaf, boxes, ids_a, inner);
         }
-        int rc = scan_exclusive(st, mem, inner, offsets, m, total, sums);
+        uint32_t* total_word = nullptr;
+        if (mailbox_arm(ctx, 0, &total_word) != hipSuccess) { pt_set_error("pt_build_sah: no mapped host memory"); return PT_ERROR_OUT_OF_MEMORY; }
+        int rc = scan_exclusive(st, mem, inner, offsets, m, total_word, sums);
         if (rc) return rc;
+        // launched before the host knows whether any range was split (the flags of a last level are not used):
+        // the GPU works on it while the count travels
+        k_sah_emit_flags<<<nb, kBlock, 0, st>>>(n, ids_a, boxes, tof_a, tasks_a, flags, m, offsets, node_base, nodes);
         uint32_t n_inner = 0;
-        if (read_word(ctx, total, &n_inner) != hipSuccess) {
+        if (mailbox_wait(ctx, 0, &n_inner) != hipSuccess) {
             pt_set_error("pt_build_sah: %s", hipGetErrorString(hipGetLastError())); return PT_ERROR_HIP;
         }
-        k_sah_emit<<<div_up(m, kBlock), kBlock, 0, st>>>(m, tasks_a, offsets, node_base, nodes);
         if (n_inner) {
-            k_sah_flags<<<nb, kBlock, 0, st>>>(n, ids_a, boxes, tof_a, tasks_a, flags);
             rc = scan_exclusive(st, mem, flags, left, n, nullptr, sums);
             if (rc) return rc;
             k_sah_scatter<<<nb, kBlock, 0, st>>>(n, ids_a, tof_a, tasks_a, offsets, flags, left, ids_b, tof_b, tasks_b);
@@ -768,10 +838,10 @@ int pt_build_sah(PtContext* ctx, const float* boxes, uint32_t n, uint32_t max_le
         }
         node_base += n_inner; m = 2 * n_inner;
     }
+    // the scratch of this build goes back to the arena here; what comes next on the stream may reuse it, in order
+    PT_HIP_CHECK(hipMemcpyAsync(*order_out, ids_a, sizeof(uint32_t) * n, hipMemcpyDeviceToDevice, st));
     PT_HIP_CHECK(hipGetLastError());
-    PT_HIP_CHECK(hipStreamSynchronize(st));
-    mem.release(nodes); mem.release(ids_a);
-    *nodes_out = nodes; *node_count_out = node_base; *order_out = ids_a;
+    *node_count_out = node_base;
     return PT_OK;
 }
 
@@ -779,25 +849,29 @@ int pt_build_wide(PtContext* ctx, const PtBvhNode* nodes_dev, uint32_t node_coun
 {
     hipStream_t st = ctx->stream;
     DevMem mem(ctx);
-    uint32_t *front_a = nullptr, *front_b = nullptr, *counts = nullptr, *offsets = nullptr, *total = nullptr;
+    uint32_t *front_a = nullptr, *front_b = nullptr, *counts = nullptr, *offsets = nullptr, *sums = nullptr;
     PtWide4* wide = nullptr;
     // every wide node stands for a distinct binary node
     PT_HIP_CHECK(mem.alloc(&front_a, node_count)); PT_HIP_CHECK(mem.alloc(&front_b, node_count));
-    PT_HIP_CHECK(mem.alloc(&counts, node_count)); PT_HIP_CHECK(mem.alloc(&offsets, node_count)); PT_HIP_CHECK(mem.alloc(&total, 4));
-    PT_HIP_CHECK(hipMalloc((void**)&wide, sizeof(PtWide4) * (size_t)node_count));
-    auto fail = [&](int code) { (void)hipFree(wide); return code; };
+    PT_HIP_CHECK(mem.alloc(&counts, node_count)); PT_HIP_CHECK(mem.alloc(&offsets, node_count)); PT_HIP_CHECK(mem.alloc(&sums, div_up(node_count, kBlock) + 1));
+    const bool own = *wide_out == nullptr;           // otherwise the caller's buffer of node_count nodes
+    if (own) PT_HIP_CHECK(hipMalloc((void**)&wide, sizeof(PtWide4) * (size_t)node_count));
+    else wide = (PtWide4*)*wide_out;
+    auto fail = [&](int code) { if (own) (void)hipFree(wide); return code; };
     if (hipMemsetAsync(front_a, 0, 4, st) != hipSuccess) return fail(PT_ERROR_HIP);   // the root
     uint32_t n_front = 1, level_base = 0, depth = 0;
     while (n_front) {
         ++depth;
         if (level_base + n_front > node_count || depth > 4096) { pt_set_error("pt_build_wide: the binary tree is not a tree"); return fail(PT_ERROR_HIP); }
         const uint32_t nb = div_up(n_front, kBlock);
+        uint32_t* total_word = nullptr;
+        if (mailbox_arm(ctx, 1, &total_word) != hipSuccess) { pt_set_error("pt_build_wide: no mapped host memory"); return fail(PT_ERROR_OUT_OF_MEMORY); }
         k_wide_count<<<nb, kBlock, 0, st>>>(nodes_dev, front_a, n_front, counts);
-        int rc = scan_exclusive(st, mem, counts, offsets, n_front, total);
+        int rc = scan_exclusive(st, mem, counts, offsets, n_front, total_word, sums);
         if (rc) return fail(rc);
         k_wide_emit<<<nb, kBlock, 0, st>>>(nodes_dev, front_a, n_front, offsets, level_base, wide, front_b);
         uint32_t next = 0;
-        if (read_word(ctx, total, &next) != hipSuccess) {
+        if (mailbox_wait(ctx, 1, &next) != hipSuccess) {
             pt_set_error("pt_build_wide: %s", hipGetErrorString(hipGetLastError())); return fail(PT_ERROR_HIP);
         }
         level_base += n_front; n_front = next;
@@ -898,8 +972,9 @@ struct EventPair {
 };
 static void blas_free(PtBlas* b)
 {
-    (void)hipFree(b->nodes); (void)hipFree(b->tris); (void)hipFree(b->leaf_prims); (void)hipFree(b->sorted_keys); (void)hipFree(b->wide);
-    (void)hipFree(b->trav_nodes); (void)hipFree(b->trav_order);
+    (void)hipFree(b->nodes); (void)hipFree(b->leaf_prims); (void)hipFree(b->sorted_keys);
+    if (b->block) (void)hipFree(b->block);       // tris, wide, trav_nodes and trav_order are parts of it
+    else { (void)hipFree(b->tris); (void)hipFree(b->wide); (void)hipFree(b->trav_nodes); (void)hipFree(b->trav_order); }
     delete b;
 }
 static void tlas_free(PtTlas* t)      // nothing in flight may still traverse the pool
@@ -920,6 +995,41 @@ struct Owner {
 // =============================================================================================
 extern "C" {
 
+// Padded primitive boxes of a BLAS (6 floats each) and scal: [0] bits of the largest |coordinate|, [1..6] the root
+// box as ordered uints.
+static int blas_boxes(PtContext* ctx, DevMem& mem, const uint8_t* v, uint32_t vertex_stride, const uint32_t* indices_dev,
+                      uint32_t prim_count, uint32_t** scal_out, float** boxes_out)
+{
+    hipStream_t st = ctx->stream;
+    uint32_t* scal = nullptr; float* boxes = nullptr;
+    PT_HIP_CHECK(mem.alloc(&scal, 8));
+    PT_HIP_CHECK(mem.alloc(&boxes, (size_t)prim_count * 6));
+    PT_HIP_CHECK(hipMemsetAsync(scal, 0, 4, st));
+    PT_HIP_CHECK(hipMemsetAsync(scal + 1, 0xFF, 12, st));
+    PT_HIP_CHECK(hipMemsetAsync(scal + 4, 0x00, 12, st));
+    const uint32_t nb = div_up(prim_count, kBlock);
+    k_blas_maxabs<<<nb, kBlock, 0, st>>>(v, vertex_stride, indices_dev, prim_count, scal);
+    k_tri_boxes<<<nb, kBlock, 0, st>>>(v, vertex_stride, indices_dev, prim_count, scal, boxes, scal + 1);
+    PT_HIP_CHECK(hipGetLastError());
+    *scal_out = scal; *boxes_out = boxes;
+    return PT_OK;
+}
+
+// The Morton-order tree of a BLAS (what pt_blas_download returns).  The kernels traverse the binned-SAH tree, so
+// this one is built when it is first asked for; the vertex and index buffers given to pt_blas_build must still
+// hold the same data then (they must anyway: shading reads them).
+static int blas_ensure_morton(PtBlas* b)
+{
+    if (b->nodes) return PT_OK;
+    PtContext* ctx = b->ctx;
+    PT_HIP_CHECK(hipSetDevice(ctx->device));
+    DevMem mem(ctx);
+    uint32_t* scal = nullptr; float* boxes = nullptr;
+    int rc = blas_boxes(ctx, mem, b->vertices, b->stride, b->indices, b->prim_count, &scal, &boxes);
+    if (rc) return rc;
+    return pt_build_lbvh(ctx, boxes, b->prim_count, b->max_leaf, &b->nodes, &b->node_count, &b->leaf_prims, &b->sorted_keys);
+}
+
 int pt_blas_build(PtContext* ctx, const void* vertices_dev, uint32_t vertex_stride, uint32_t max_vertex,
                   const uint32_t* indices_dev, uint32_t prim_count, uint32_t max_leaf, PtBlas** out)
 {
@@ -937,37 +1047,44 @@ int pt_blas_build(PtContext* ctx, const void* vertices_dev, uint32_t vertex_stri
     PT_HIP_CHECK(hipEventRecord(ev0, st));
     DevMem mem(ctx);
     uint32_t* scal = nullptr; float* boxes = nullptr;
-    PT_HIP_CHECK(mem.alloc(&scal, 8));          // [0] maxabs bits, [1..6] root box (ordered)
-    PT_HIP_CHECK(mem.alloc(&boxes, (size_t)prim_count * 6));
-    PT_HIP_CHECK(hipMemsetAsync(scal, 0, 4, st));
-    PT_HIP_CHECK(hipMemsetAsync(scal + 1, 0xFF, 12, st));
-    PT_HIP_CHECK(hipMemsetAsync(scal + 4, 0x00, 12, st));
-    uint32_t nb = div_up(prim_count, kBlock);
+    const uint32_t nb = div_up(prim_count, kBlock);
     const uint8_t* v = (const uint8_t*)vertices_dev;
-    k_blas_maxabs<<<nb, kBlock, 0, st>>>(v, vertex_stride, indices_dev, prim_count, scal);
-    k_tri_boxes<<<nb, kBlock, 0, st>>>(v, vertex_stride, indices_dev, prim_count, scal, boxes, scal + 1);
-    PT_HIP_CHECK(hipGetLastError());
+    int rc = blas_boxes(ctx, mem, v, vertex_stride, indices_dev, prim_count, &scal, &boxes);
+    if (rc) return rc;
     PtBlas* b = new PtBlas();
     memset(b, 0, sizeof *b);
     Owner<PtBlas, blas_free> owner(b);
     b->ctx = ctx; b->vertices = v; b->stride = vertex_stride; b->max_vertex = max_vertex;
     b->indices = indices_dev; b->prim_count = prim_count; b->max_leaf = max_leaf;
-    int rc = pt_build_lbvh(ctx, boxes, prim_count, max_leaf, &b->nodes, &b->node_count, &b->leaf_prims, &b->sorted_keys);
-    if (rc) return rc;
     // The kernels traverse a binned-SAH tree (16-18 % fewer box tests than the Morton tree on the dragon
-    // meshes); PT_HIP_TRAVERSAL_TREE=lbvh keeps the Morton tree for both purposes.
+    // meshes), and the Morton tree is left to blas_ensure_morton; PT_HIP_TRAVERSAL_TREE=lbvh (and a BLAS of
+    // one primitive) uses the Morton tree for both purposes.
     const char* tree_env = getenv("PT_HIP_TRAVERSAL_TREE");
-    const uint32_t* trav_order = b->leaf_prims;      // leaf order of the tree the kernels traverse
+    const uint32_t* trav_order = nullptr;            // leaf order of the tree the kernels traverse
     if (!(tree_env && strcmp(tree_env, "lbvh") == 0) && prim_count > 1) {
+        // one allocation for what outlives the build (an allocation costs as much as twenty of the kernels):
+        // binary nodes (at most n - 1), wide nodes (at most as many), triangle records, leaf order
+        const size_t n = prim_count;
+        if (hipMalloc(&b->block, n * (sizeof(PtBvhNode) + sizeof(PtWide4) + 3 * sizeof(float4) + sizeof(uint32_t))) != hipSuccess) {
+            pt_set_error("pt_blas_build: out of memory"); return PT_ERROR_OUT_OF_MEMORY;
+        }
+        b->trav_nodes = (PtBvhNode*)b->block;
+        b->wide = (char*)b->block + n * sizeof(PtBvhNode);
+        b->tris = (float4*)((char*)b->wide + n * sizeof(PtWide4));
+        b->trav_order = (uint32_t*)((char*)b->tris + n * 3 * sizeof(float4));
         rc = pt_build_sah(ctx, boxes, prim_count, max_leaf, scal + 1, &b->trav_nodes, &b->trav_node_count, &b->trav_order);
         if (rc) return rc;
         trav_order = b->trav_order;
         rc = pt_build_wide(ctx, b->trav_nodes, b->trav_node_count, &b->wide, &b->wide_count, &b->wide_depth);
-    } else
+    } else {
+        rc = pt_build_lbvh(ctx, boxes, prim_count, max_leaf, &b->nodes, &b->node_count, &b->leaf_prims, &b->sorted_keys);
+        if (rc) return rc;
+        trav_order = b->leaf_prims;
         rc = pt_build_wide(ctx, b->nodes, b->node_count, &b->wide, &b->wide_count, &b->wide_depth);
+    }
     if (rc) return rc;
     uint32_t host_scal[7];
-    hipError_t e = hipMalloc((void**)&b->tris, sizeof(float4) * 3 * (size_t)prim_count);
+    hipError_t e = b->tris ? hipSuccess : hipMalloc((void**)&b->tris, sizeof(float4) * 3 * (size_t)prim_count);
     if (e == hipSuccess) {
         k_pack_tris<<<nb, kBlock, 0, st>>>(v, vertex_stride, indices_dev, trav_order, prim_count, b->tris);
         e = hipMemcpyAsync(host_scal, scal, sizeof host_scal, hipMemcpyDeviceToHost, st);
@@ -1042,6 +1159,7 @@ int pt_tlas_wide_download(const PtTlas* t, void* nodes64, uint32_t capacity, uin
 int pt_blas_download(const PtBlas* b, PtBvhNode* nodes, uint32_t* leaf_prims, uint64_t* sorted_keys)
 {
     PT_REQUIRE(b, "null argument");
+    if (int rc = blas_ensure_morton(const_cast<PtBlas*>(b))) return rc;
     PT_HIP_CHECK(hipSetDevice(b->ctx->device));
     if (nodes) PT_HIP_CHECK(hipMemcpy(nodes, b->nodes, sizeof(PtBvhNode) * b->node_count, hipMemcpyDeviceToHost));
     if (leaf_prims) PT_HIP_CHECK(hipMemcpy(leaf_prims, b->leaf_prims, sizeof(uint32_t) * b->prim_count, hipMemcpyDeviceToHost));

@@ -144,6 +144,7 @@ int pt_ctx_destroy(PtContext* c)
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     for (auto& ch : c->build_arena.chunks) (void)hipFree(ch.first);
     if (c->pinned_word) (void)hipHostFree(c->pinned_word);
+    if (c->mailbox) (void)hipHostFree(c->mailbox);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return PT_OK;

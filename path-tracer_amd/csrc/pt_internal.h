@@ -62,6 +62,7 @@ struct PtBlas {
     uint32_t* trav_order;    // device: primitive at each leaf position of that tree (tris follow it)
     void* wide;              // device: 64-byte 4-wide quantised nodes of this BLAS, references local (root 0, triangle 0)
     uint32_t wide_count, wide_depth;
+    void* block;             // device: the one allocation trav_nodes, wide, tris and trav_order are parts of (null: each has its own)
     float build_ms;
 };
 
@@ -160,6 +161,8 @@ struct PtContext {
     std::vector<uint8_t> ev_primary;           // per pair: the launch was bounce 0 (k_primary)
     PtArena build_arena;
     uint32_t* pinned_word = nullptr;           // pinned host word for single-value readbacks
+    uint32_t* mailbox = nullptr;               // mapped, coherent host words that kernels write and the host polls (per-level totals of the builders)
+    uint32_t* mailbox_dev = nullptr;           // ... as the device addresses them
     std::vector<uint32_t> ev_depth;            // depth of each recorded pair
     uint64_t stats_mark[PT_MAX_DEPTH] = {};    // rays_per_depth at the last pt_trace_profile
 };

@@ -180,6 +180,8 @@ class BottomLevelAccelerationStructure:
         return out[0]
 
     def download(self):
+        """The Morton-order tree (built by the first call: the kernels traverse the SAH tree)."""
+        _check(self.ctx.lib.pt_blas_download(self.h, None, None, None))
         info = self.info()
         nodes = np.zeros(int(info["node_count"]), dtype=abi.BVH_NODE)
         prims = np.zeros(self.prim_count, dtype=np.uint32)
