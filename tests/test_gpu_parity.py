@@ -39,7 +39,12 @@ def test_bvh_topology_bit_exact(name, request):
     r = _renderer(scene, 8, 8)
     try:
         for i, (ob, gb) in enumerate(zip(orc.blases, r.blases)):
+            if gb.prim_count > 1:       # the kernels traverse the SAH tree: the Morton tree exists from its first download on
+                assert int(gb.info()["node_count"]) == 0
             nodes, prims, keys = gb.download()
+            assert int(gb.info()["node_count"]) == len(nodes) > 0
+            again = gb.download()
+            assert all(np.array_equal(a.view(np.uint8), b.view(np.uint8)) for a, b in zip((nodes, prims, keys), again))
             assert np.array_equal(keys, ob.sorted_keys()), f"blas {i}: sorted Morton keys differ"
             assert np.array_equal(prims, ob.leaf_prims()), f"blas {i}: primitive order differs"
             on = ob.nodes()
