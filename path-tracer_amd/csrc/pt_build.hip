@@ -429,6 +429,28 @@ __global__ void k_wide_emit(const PtBvhNode* __restrict__ n2, const uint32_t* __
     out[level_base + i] = w;
 }
 
+// The pool's nodes with their planes expanded to floats by the arithmetic the quantised traversal step uses.
+__global__ void k_wide_expand(const PtWide4* __restrict__ in, uint32_t n, PtWideF* __restrict__ out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const PtWide4 w = in[i];
+    PtWideF f;
+    const float inf = __builtin_inff();
+    for (int e = 0; e < 4; ++e) {
+        const bool empty = w.child[e] == PT_WIDE_EMPTY;
+        f.lo_x[e] = empty ? inf : pt_grid_plane((w.q[0] >> (8 * e)) & 255u, w.scale_x, w.origin[0]);
+        f.lo_y[e] = empty ? inf : pt_grid_plane((w.q[1] >> (8 * e)) & 255u, w.scale_y, w.origin[1]);
+        f.lo_z[e] = empty ? inf : pt_grid_plane((w.q[2] >> (8 * e)) & 255u, w.scale_z, w.origin[2]);
+        f.hi_x[e] = empty ? -inf : pt_grid_plane((w.q[3] >> (8 * e)) & 255u, w.scale_x, w.origin[0]);
+        f.hi_y[e] = empty ? -inf : pt_grid_plane((w.q[4] >> (8 * e)) & 255u, w.scale_y, w.origin[1]);
+        f.hi_z[e] = empty ? -inf : pt_grid_plane((w.q[5] >> (8 * e)) & 255u, w.scale_z, w.origin[2]);
+        f.child[e] = w.child[e];
+        f.pad[e] = 0u;
+    }
+    out[i] = f;
+}
+
 // Copies wide nodes into a pool: inner references move by node_base, triangle positions by tri_base.
 __global__ void k_wide_rebase(const PtWide4* __restrict__ in, uint32_t n, uint32_t node_base, uint32_t tri_base, PtWide4* __restrict__ out)
 {
@@ -981,7 +1003,7 @@ static void tlas_free(PtTlas* t)      // nothing in flight may still traverse th
 {
     (void)hipFree(t->nodes); (void)hipFree(t->leaf_inst); (void)hipFree(t->inst); (void)hipFree(t->shade_inst);
     for (auto& r : t->tri_records) (void)hipFree(r.dev);
-    (void)hipFree(t->pool_nodes); (void)hipFree(t->pool_tris);
+    (void)hipFree(t->pool_nodes); (void)hipFree(t->pool_nodes_f32); (void)hipFree(t->pool_tris);
     delete t;
 }
 template <typename T, void (*FREE)(T*)>
@@ -1204,7 +1226,7 @@ int pt_tlas_build(PtContext* ctx, const PtInstance* instances, uint32_t n, PtTla
     PtTlas* t = new PtTlas();
     Owner<PtTlas, tlas_free> owner(t);        // nothing traverses a structure that is still being built
     t->ctx = ctx; t->n = n; t->nodes = nullptr; t->leaf_inst = nullptr; t->inst = nullptr; t->shade_inst = nullptr;
-    t->pool_nodes = nullptr; t->pool_tris = nullptr; t->pool_node_count = 0;
+    t->pool_nodes = nullptr; t->pool_nodes_f32 = nullptr; t->pool_tris = nullptr; t->pool_node_count = 0;
     t->host_boxes.resize((size_t)n * 6); t->host_w2o.resize((size_t)n * 12);
     std::vector<PtDevInstance> di(n);
     t->host_o2w.resize((size_t)n * 12); t->host_custom.resize(n); t->host_prim_count.resize(n); t->shade_version = 0;
@@ -1306,6 +1328,10 @@ int pt_tlas_build(PtContext* ctx, const PtInstance* instances, uint32_t n, PtTla
             for (size_t k = 0; k < uniq.size(); ++k)
                 k_wide_rebase<<<div_up(uniq[k]->wide_count, kBlock), kBlock, 0, st>>>((const PtWide4*)uniq[k]->wide, uniq[k]->wide_count, root_of[k], tri_base[k], (PtWide4*)t->pool_nodes);
             e = hipGetLastError();
+        }
+        if (e == hipSuccess) {       // the same nodes with float planes, for the kernel whose waves walk them in step
+            e = hipMalloc(&t->pool_nodes_f32, sizeof(PtWideF) * (size_t)total_nodes);
+            if (e == hipSuccess) k_wide_expand<<<div_up(total_nodes, kBlock), kBlock, 0, st>>>((const PtWide4*)t->pool_nodes, total_nodes, (PtWideF*)t->pool_nodes_f32);
         }
         for (size_t k = 0; k < uniq.size() && e == hipSuccess; ++k)
             e = hipMemcpyAsync(t->pool_tris + 3 * (size_t)tri_base[k], uniq[k]->tris, sizeof(float4) * 3 * (size_t)uniq[k]->prim_count, hipMemcpyDeviceToDevice, st);

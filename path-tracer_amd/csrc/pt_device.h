@@ -128,6 +128,7 @@ __device__ __forceinline__ void pt_hit_update(PtHitRec& best, float t, uint32_t 
 // references, and the triangle records of every BLAS; a node is four float4, a triangle three.
 struct PtTlasView {
     const float4* nodes;
+    const float4* nodes_f32;       // the same nodes as PtWideF (128 bytes each)
     const float4* tris;
     const PtDevInstance* inst;     // in the order of the TLAS leaf slots
 };
@@ -196,17 +197,46 @@ typedef PtStackT<PT_LDS_STACK, 1> PtStack;
 // byte k of each word belongs to child k and a plane is fma(byte, step, origin).
 // Continues with the nearest child that the ray interval [tlo, hi] overlaps and pushes the others
 // so that nearer ones are popped first; returns the next item (a pop if nothing was hit).
-template <typename STACK>
+// F32 = false: the 64-byte node above.  F32 = true: the same node as 128 bytes with its planes as floats
+// (PtWideF: [lo.x hi.x lo.y hi.y lo.z hi.z] x four children, then the references).  The nearer plane vector of an
+// axis is the low one when 1/d > 0, and the ray's sign picks it by address, so the step needs neither the 24 byte
+// conversions and first fmas nor the word selects: 99 vector instructions instead of 153.  It also loads seven
+// 16-byte vectors per lane instead of four, which costs incoherent rays more than the instructions save
+// (k_intersect +3 %); where the 64 lanes of a wave walk the same nodes the loads are broadcasts (k_primary -10 %).
+template <bool F32, typename STACK>
 __device__ __forceinline__ int pt_wide_step(const PtRaySpace& r, const float4* __restrict__ nodes, int node,
                                             float tlo, float hi, STACK& stk)
 {
+    float tn[4]; int ref[4];
+    const float inf = __builtin_inff();
+    if constexpr (F32) {
+    const uint32_t base = (uint32_t)node << 7;
+    const uint32_t sx = (__float_as_uint(r.ix) >> 27) & 16u, sy = (__float_as_uint(r.iy) >> 27) & 16u, sz = (__float_as_uint(r.iz) >> 27) & 16u;
+    const char* pool = (const char*)nodes;
+    // (offsets are unsigned 32-bit: the subtraction comes after the addition, so that node 0 does not wrap)
+    const float4 nx4 = *(const float4*)(pool + (base + sx)), fx4 = *(const float4*)(pool + ((base + 16u) - sx));
+    const float4 ny4 = *(const float4*)(pool + (base + 32u + sy)), fy4 = *(const float4*)(pool + ((base + 48u) - sy));
+    const float4 nz4 = *(const float4*)(pool + (base + 64u + sz)), fz4 = *(const float4*)(pool + ((base + 80u) - sz));
+    const float4 rf = *(const float4*)(pool + (base + 96u));
+    const float nxv[4] = { nx4.x, nx4.y, nx4.z, nx4.w }, fxv[4] = { fx4.x, fx4.y, fx4.z, fx4.w };
+    const float nyv[4] = { ny4.x, ny4.y, ny4.z, ny4.w }, fyv[4] = { fy4.x, fy4.y, fy4.z, fy4.w };
+    const float nzv[4] = { nz4.x, nz4.y, nz4.z, nz4.w }, fzv[4] = { fz4.x, fz4.y, fz4.z, fz4.w };
+    ref[0] = __float_as_int(rf.x); ref[1] = __float_as_int(rf.y); ref[2] = __float_as_int(rf.z); ref[3] = __float_as_int(rf.w);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float ax = PT_FMA(nxv[k], r.ix, -r.oox), ay = PT_FMA(nyv[k], r.iy, -r.ooy), az = PT_FMA(nzv[k], r.iz, -r.ooz);
+        const float bx = PT_FMA(fxv[k], r.ix, -r.oox), by = PT_FMA(fyv[k], r.iy, -r.ooy), bz = PT_FMA(fzv[k], r.iz, -r.ooz);
+        const float a = fmaxf(fmaxf(ax, ay), az), b = fminf(fminf(bx, by), bz);
+        const bool hit = fmaxf(a, tlo) <= fminf(b, hi);      // an empty child is (+inf, -inf)
+        tn[k] = hit ? a : inf;
+    }
+    } else {
     const float4 h0 = nodes[4 * (size_t)node + 0], h1 = nodes[4 * (size_t)node + 1];
     const float4 h2 = nodes[4 * (size_t)node + 2], h3 = nodes[4 * (size_t)node + 3];
     const float sx = h0.w, sy = h3.z, sz = h3.w;
     const uint32_t Lx = __float_as_uint(h2.x), Ly = __float_as_uint(h2.y), Lz = __float_as_uint(h2.z);
     const uint32_t Hx = __float_as_uint(h2.w), Hy = __float_as_uint(h3.x), Hz = __float_as_uint(h3.y);
     const int ref_in[4] = { __float_as_int(h1.x), __float_as_int(h1.y), __float_as_int(h1.z), __float_as_int(h1.w) };
-    const float inf = __builtin_inff();
     // The plane distance fma(x, 1/d, -o/d) is monotone in x, so the nearer plane of an axis is the
     // low one when 1/d > 0 and the high one otherwise: picking the plane words by the sign gives
     // the same interval as taking min and max of both distances.
@@ -214,7 +244,6 @@ __device__ __forceinline__ int pt_wide_step(const PtRaySpace& r, const float4* _
     const uint32_t Nx = nx ? Hx : Lx, Fx = nx ? Lx : Hx;
     const uint32_t Ny = ny ? Hy : Ly, Fy = ny ? Ly : Hy;
     const uint32_t Nz = nz ? Hz : Lz, Fz = nz ? Lz : Hz;
-    float tn[4]; int ref[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const float ax = PT_FMA(PT_FMA((float)((Nx >> (8 * k)) & 255u), sx, h0.x), r.ix, -r.oox);
@@ -227,6 +256,7 @@ __device__ __forceinline__ int pt_wide_step(const PtRaySpace& r, const float4* _
         const bool hit = (ref_in[k] != PT_NODE_EMPTY) && fmaxf(a, tlo) <= fminf(b, hi);
         tn[k] = hit ? a : inf;
         ref[k] = ref_in[k];
+    }
     }
 #ifndef PT_NO_UNIFORM_SKIP
     // Ordering matters only where a lane has two or more children to go on with; when no lane of the wave has
@@ -265,6 +295,7 @@ __device__ __forceinline__ void pt_to_object_space(const float4 r0, const float4
 // Closest hit = lexicographic minimum of (t, instance, primitive) over every triangle passing the
 // gated test with tmin < t < tmax and t inside the instance's world-box interval.
 // Plain form: one ray per lane from start to end (the wave-scheduled form is in pt_traverse_sched.h).
+template <bool F32>
 __device__ __forceinline__ void pt_closest_hit(const PtTlasView& tl, PtStack& stk, float ox, float oy, float oz,
                                                float dx, float dy, float dz, float tmin, float tmax, PtHitRec& best)
 {
@@ -279,7 +310,7 @@ __device__ __forceinline__ void pt_closest_hit(const PtTlasView& tl, PtStack& st
     int node = 0;
     for (;;) {
         while ((unsigned)node < (unsigned)PT_NODE_DONE)
-            node = pt_wide_step(cur, tl.nodes, node, tlo, fminf(thi, best.t), stk);
+            node = pt_wide_step<F32>(cur, F32 ? tl.nodes_f32 : tl.nodes, node, tlo, fminf(thi, best.t), stk);
         if (node == PT_NODE_DONE) break;
         if (node == PT_NODE_SENTINEL) {      // all of the instance's BLAS visited: back to world space
             cur_inst = PT_NO_INSTANCE; cur = ws; tlo = tmin; thi = tmax;

@@ -72,6 +72,7 @@ struct PtTlas {
     uint32_t node_count;
     PtBvhNode* nodes;               // device: TLAS nodes alone (what pt_tlas_download returns)
     void* pool_nodes;               // device: 64-byte 4-wide quantised nodes, TLAS first then every distinct BLAS, references absolute
+    void* pool_nodes_f32;           // device: the same nodes as 128-byte PtWideF (float planes), what k_primary traverses
     float4* pool_tris;              // device: triangle records of every distinct BLAS, 3 float4 each
     uint32_t pool_node_count;
     uint32_t wide_count, wide_depth;  // the TLAS's own wide nodes: the first wide_count of the pool

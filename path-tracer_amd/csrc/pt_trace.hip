@@ -197,7 +197,7 @@ k_intersect(PtTlasView tl, uint32_t* __restrict__ counters, uint32_t depth, uint
         if (valid) {
             const float4 o = q0[i], d = q1[i];
             PtHitRec h;
-            pt_closest_hit(tl, stk, o.x, o.y, o.z, d.x, d.y, d.z, tmin, tmax, h);
+            pt_closest_hit<false>(tl, stk, o.x, o.y, o.z, d.x, d.y, d.z, tmin, tmax, h);
             PtHit out; out.instance = h.inst; out.primitive = h.prim; out.u = h.u; out.v = h.v;
             const uint32_t dst = BY_ID ? __float_as_uint(d.w) : i;
             hits[dst] = out;
@@ -523,6 +523,9 @@ k_shade(PtShadeArgs A, const PtHit* __restrict__ hits)
 #ifndef PT_PRIMARY_WAVES
 #define PT_PRIMARY_WAVES 4
 #endif
+#ifndef PT_PRIMARY_F32
+#define PT_PRIMARY_F32 true        // the 64 lanes of a wave hold one pixel's samples and walk the same nodes: float planes, loads are broadcasts
+#endif
 __global__ void __launch_bounds__(kBlock, PT_PRIMARY_WAVES)
 k_primary(PtTlasView tl, PtShadeArgs A, float tmin, float tmax, int* __restrict__ spill)
 {
@@ -536,7 +539,7 @@ k_primary(PtTlasView tl, PtShadeArgs A, float tmin, float tmax, int* __restrict_
             float ox, oy, oz, dx, dy, dz;
             pt_primary_ray(A.primary, path_of_slot(i, shard, A.shard_cap), ox, oy, oz, dx, dy, dz);
             PtHitRec r;
-            pt_closest_hit(tl, stk, ox, oy, oz, dx, dy, dz, tmin, tmax, r);
+            pt_closest_hit<PT_PRIMARY_F32>(tl, stk, ox, oy, oz, dx, dy, dz, tmin, tmax, r);
             h.instance = r.inst; h.primitive = r.prim; h.u = r.u; h.v = r.v;
         }
         shade_batch<true>(A, A.shade_inst, A.o0, A.o1, A.o2, A.o3, A.path_result, i, valid, shard, h,
@@ -755,7 +758,7 @@ uint32_t sched_threshold(const PtContext* ctx, uint32_t depth)
 PtTlasView view_of(const PtTlas* t)
 {
     PtTlasView v;
-    v.nodes = (const float4*)t->pool_nodes; v.tris = t->pool_tris; v.inst = t->inst;
+    v.nodes = (const float4*)t->pool_nodes; v.nodes_f32 = (const float4*)t->pool_nodes_f32; v.tris = t->pool_tris; v.inst = t->inst;
     return v;
 }
 
@@ -817,7 +820,7 @@ extern "C" int pt_intersect_noalloc(PtContext* ctx, const PtTlas* tlas, uint32_t
     // the array keeps what the last call left: sizes and work counters start at zero
     PT_HIP_CHECK(hipMemsetAsync(counters, 0, sizeof(uint32_t) * kCounterWords, st));
     k_pack_rays<<<(n + kBlock - 1) / kBlock, kBlock, 0, st>>>(n, cap, origins_dev, dirs_dev, q0, q1, counters);
-    PtTlasView tv; tv.nodes = (const float4*)tlas->pool_nodes; tv.tris = tlas->pool_tris; tv.inst = tlas->inst;
+    PtTlasView tv = view_of(tlas);
     const uint32_t thr = ctx->traversal_mode == 0 ? 0xFFFFFFFFu : (ctx->traversal_mode == 1 ? 0u : ctx->sched_min_rays);   // mode 3 (two rays per lane) needs twice the stack slices: not used here
     k_intersect<true><<<g_na_blocks[ctx->device], kBlock, 0, st>>>(tv, counters, 0, cap, q0, q1, tmin, tmax, hits_dev, t_dev, spill, thr);
     PT_HIP_CHECK(hipGetLastError());

@@ -221,7 +221,7 @@ __device__ __forceinline__ void pt_traverse_pair(const PtTlasView& tl, const PtS
                 { const int act_ = __popcll(__ballot(act)); (void)act_; PT_STAT(0, 1); PT_STAT(3, act_); }
                 if (act) {
                     stk.sp = A.sp;
-                    const int next = pt_wide_step(space(), tl.nodes, A.node, A.tlo, fminf(A.thi, A.best_t), stk);
+                    const int next = pt_wide_step<false>(space(), tl.nodes, A.node, A.tlo, fminf(A.thi, A.best_t), stk);
                     if ((unsigned)next < (unsigned)PT_NODE_DONE) A.node = next; else advance(next);
                     A.sp = stk.sp;
                 }

@@ -198,7 +198,7 @@ __device__ __forceinline__ void pt_traverse_sched(const PtTlasView& tl, const Pt
             do {
                 { const int act_ = __popcll(__ballot(want_node)); (void)act_; PT_STAT(0, 1); PT_STAT(3, act_); }
                 if (want_node) {
-                    const int next = pt_wide_step(cur, tl.nodes, node, tlo, fminf(thi, best_t), stk);
+                    const int next = pt_wide_step<false>(cur, tl.nodes, node, tlo, fminf(thi, best_t), stk);
                     if ((unsigned)next < (unsigned)PT_NODE_DONE) node = next; else advance(next);
                     want_node = (unsigned)node < (unsigned)PT_NODE_DONE;
                 }

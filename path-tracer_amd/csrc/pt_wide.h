@@ -27,6 +27,15 @@ struct PtWide4 {
 };
 static_assert(sizeof(PtWide4) == 64, "wide node must be 64 bytes");
 
+// The same node with its planes as floats, one plane of the four children per 16 bytes: a kernel that picks the
+// near and far plane vectors by address (the ray's sign offsets the load) needs neither byte conversions nor selects.
+struct PtWideF {
+    float lo_x[4], hi_x[4], lo_y[4], hi_y[4], lo_z[4], hi_z[4];    // an empty child is (+inf, -inf): no ray interval overlaps it
+    int32_t child[4];
+    uint32_t pad[4];
+};
+static_assert(sizeof(PtWideF) == 128, "float wide node must be 128 bytes");
+
 #if defined(__HIPCC__)
 #define PT_HD __host__ __device__
 #else
