@@ -743,6 +743,7 @@ hipError_t read_word(PtContext* ctx, const uint32_t* dev, uint32_t* out)
 constexpr uint32_t kMailboxEmpty = 0xFFFFFFFFu;
 hipError_t mailbox_arm(PtContext* ctx, int slot, uint32_t** dev_word)
 {
+    if (getenv("PT_HIP_NO_MAILBOX")) return hipErrorNotSupported;      // for testing the other path
     if (!ctx->mailbox) {
         hipError_t e = hipHostMalloc((void**)&ctx->mailbox, 256, hipHostMallocMapped | hipHostMallocCoherent);
         if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&ctx->mailbox_dev, ctx->mailbox, 0);
@@ -768,6 +769,21 @@ hipError_t mailbox_wait(PtContext* ctx, int slot, uint32_t* out)
     *out = v;
     return hipSuccess;
 }
+
+// One per-level count: through the mailbox where mapped host memory is to be had, else through a device word,
+// a copy and a wait for the stream.
+struct LevelCount {
+    PtContext* ctx; int slot; uint32_t* dev_fallback; bool polled = false;
+    LevelCount(PtContext* c, int s, uint32_t* fallback) : ctx(c), slot(s), dev_fallback(fallback) {}
+    uint32_t* arm()
+    {
+        uint32_t* w = nullptr;
+        polled = mailbox_arm(ctx, slot, &w) == hipSuccess;
+        if (!polled) (void)hipGetLastError();
+        return polled ? w : dev_fallback;
+    }
+    hipError_t wait(uint32_t* out) { return polled ? mailbox_wait(ctx, slot, out) : read_word(ctx, dev_fallback, out); }
+};
 
 int scan_exclusive(hipStream_t st, DevMem& mem, const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* total_dev, uint32_t* sums = nullptr)
 {
@@ -815,16 +831,17 @@ int pt_build_sah(PtContext* ctx, const float* boxes, uint32_t n, uint32_t max_le
     DevMem mem(ctx);
     const uint32_t kBatch = 32768;                      // ranges whose bins are resident at once (44 MB)
     uint32_t *ids_a = nullptr, *ids_b = nullptr, *tof_a = nullptr, *tof_b = nullptr, *flags = nullptr, *left = nullptr;
-    uint32_t *inner = nullptr, *offsets = nullptr;
+    uint32_t *inner = nullptr, *offsets = nullptr, *total_dev = nullptr;
     PtSahTask *tasks_a = nullptr, *tasks_b = nullptr; SahBinsOrd* bins = nullptr; PtBvhNode* nodes = *nodes_out; uint32_t* sums = nullptr;
     PT_REQUIRE(nodes && *order_out, "pt_build_sah: output buffers missing");
     hipError_t e = hipSuccess;
     if ((e = mem.alloc(&ids_a, n)) || (e = mem.alloc(&ids_b, n)) || (e = mem.alloc(&tof_a, n)) || (e = mem.alloc(&tof_b, n)) ||
         (e = mem.alloc(&flags, n)) || (e = mem.alloc(&left, n)) || (e = mem.alloc(&inner, n)) || (e = mem.alloc(&offsets, n)) ||
         (e = mem.alloc(&tasks_a, n)) || (e = mem.alloc(&tasks_b, n)) ||
-        (e = mem.alloc(&bins, kBatch)) || (e = mem.alloc(&sums, div_up(n, kBlock) + 1))) {
+        (e = mem.alloc(&bins, kBatch)) || (e = mem.alloc(&sums, div_up(n, kBlock) + 1)) || (e = mem.alloc(&total_dev, 4))) {
         pt_set_error("pt_build_sah: hipMalloc failed: %s", hipGetErrorString(e)); return PT_ERROR_OUT_OF_MEMORY;
     }
+    LevelCount count(ctx, 0, total_dev);
     const uint32_t nb = div_up(n, kBlock);
     k_iota<<<nb, kBlock, 0, st>>>(ids_a, n);
     PT_HIP_CHECK(hipMemsetAsync(tof_a, 0, sizeof(uint32_t) * n, st));          // every primitive in range 0
@@ -841,15 +858,14 @@ int pt_build_sah(PtContext* ctx, const float* boxes, uint32_t n, uint32_t max_le
             k_sah_bins<<<nb, kBlock, 0, st>>>(n, ids_a, boxes, tof_a, t_lo, t_hi, tasks_a, bins);
             k_sah_decide<<<mb, 64, 0, st>>>(t_lo, t_hi, tasks_a, bins, max_leaf, boxes, ids_a, inner);
         }
-        uint32_t* total_word = nullptr;
-        if (mailbox_arm(ctx, 0, &total_word) != hipSuccess) { pt_set_error("pt_build_sah: no mapped host memory"); return PT_ERROR_OUT_OF_MEMORY; }
+        uint32_t* total_word = count.arm();
         int rc = scan_exclusive(st, mem, inner, offsets, m, total_word, sums);
         if (rc) return rc;
         // launched before the host knows whether any range was split (the flags of a last level are not used):
         // the GPU works on it while the count travels
         k_sah_emit_flags<<<nb, kBlock, 0, st>>>(n, ids_a, boxes, tof_a, tasks_a, flags, m, offsets, node_base, nodes);
         uint32_t n_inner = 0;
-        if (mailbox_wait(ctx, 0, &n_inner) != hipSuccess) {
+        if (count.wait(&n_inner) != hipSuccess) {
             pt_set_error("pt_build_sah: %s", hipGetErrorString(hipGetLastError())); return PT_ERROR_HIP;
         }
         if (n_inner) {
@@ -876,6 +892,9 @@ int pt_build_wide(PtContext* ctx, const PtBvhNode* nodes_dev, uint32_t node_coun
     // every wide node stands for a distinct binary node
     PT_HIP_CHECK(mem.alloc(&front_a, node_count)); PT_HIP_CHECK(mem.alloc(&front_b, node_count));
     PT_HIP_CHECK(mem.alloc(&counts, node_count)); PT_HIP_CHECK(mem.alloc(&offsets, node_count)); PT_HIP_CHECK(mem.alloc(&sums, div_up(node_count, kBlock) + 1));
+    uint32_t* total_dev = nullptr;
+    PT_HIP_CHECK(mem.alloc(&total_dev, 4));
+    LevelCount count(ctx, 1, total_dev);
     const bool own = *wide_out == nullptr;           // otherwise the caller's buffer of node_count nodes
     if (own) PT_HIP_CHECK(hipMalloc((void**)&wide, sizeof(PtWide4) * (size_t)node_count));
     else wide = (PtWide4*)*wide_out;
@@ -886,14 +905,13 @@ int pt_build_wide(PtContext* ctx, const PtBvhNode* nodes_dev, uint32_t node_coun
         ++depth;
         if (level_base + n_front > node_count || depth > 4096) { pt_set_error("pt_build_wide: the binary tree is not a tree"); return fail(PT_ERROR_HIP); }
         const uint32_t nb = div_up(n_front, kBlock);
-        uint32_t* total_word = nullptr;
-        if (mailbox_arm(ctx, 1, &total_word) != hipSuccess) { pt_set_error("pt_build_wide: no mapped host memory"); return fail(PT_ERROR_OUT_OF_MEMORY); }
+        uint32_t* total_word = count.arm();
         k_wide_count<<<nb, kBlock, 0, st>>>(nodes_dev, front_a, n_front, counts);
         int rc = scan_exclusive(st, mem, counts, offsets, n_front, total_word, sums);
         if (rc) return fail(rc);
         k_wide_emit<<<nb, kBlock, 0, st>>>(nodes_dev, front_a, n_front, offsets, level_base, wide, front_b);
         uint32_t next = 0;
-        if (mailbox_wait(ctx, 1, &next) != hipSuccess) {
+        if (count.wait(&next) != hipSuccess) {
             pt_set_error("pt_build_wide: %s", hipGetErrorString(hipGetLastError())); return fail(PT_ERROR_HIP);
         }
         level_base += n_front; n_front = next;

@@ -432,3 +432,28 @@ def test_wide8_collapse_is_a_conservative_partition(name, request, wide_lib):
     sys.setrecursionlimit(100000)
     visit(0, 1)
     assert np.all(node_refs[1:] == 1) and node_refs[0] == 0 and np.all(item_refs == 1)
+
+
+@pytest.mark.gpu
+def test_builders_give_the_same_trees_without_the_polled_mailbox(dragon, monkeypatch):
+    """The per-level counts of the SAH and wide-node builders reach the host through a mapped word it polls;
+    where such memory cannot be had they go through a device word, a copy and a stream wait.  Both ways must
+    build the same bytes."""
+    from pt_amd import hip
+
+    def trees():
+        r = hip.Renderer(dragon, 16, 16)
+        try:
+            out = []
+            for b in r.blases:
+                nodes, order = b.download_traversal_tree()
+                wide, depth = b.download_wide()
+                out.append((nodes.tobytes(), order.tobytes(), np.asarray(wide).tobytes(), depth))
+            out.append(np.asarray(r.tlas.download_wide()[0]).tobytes() if hasattr(r.tlas, "download_wide") else b"")
+            return out
+        finally:
+            r.close()
+
+    polled = trees()
+    monkeypatch.setenv("PT_HIP_NO_MAILBOX", "1")
+    assert trees() == polled
