@@ -1226,6 +1226,12 @@ static void invert_transform(const float m[12], float w[12])
     w[8] = (float)i20; w[9] = (float)i21; w[10] = (float)i22; w[11] = (float)(-((i20 * t0 + i21 * t1) + i22 * t2));
 }
 
+// Largest TLAS whose rays start with the instances instead of the root node.  Measured on one GPU: two instances
+// (dragon scene) +4.9 % on the frame, eight (Cornell box) -27 %, six (helmet) -9 %: a missed instance costs a pass
+// of the instance phase where the root step would have culled it, so the root step pays from about three on.
+#ifndef PT_ROOT_ITEMS_DEFAULT
+#define PT_ROOT_ITEMS_DEFAULT 2u
+#endif
 #ifndef PT_TINY_BLAS
 #define PT_TINY_BLAS 4u
 #endif
@@ -1244,7 +1250,7 @@ int pt_tlas_build(PtContext* ctx, const PtInstance* instances, uint32_t n, PtTla
     PtTlas* t = new PtTlas();
     Owner<PtTlas, tlas_free> owner(t);        // nothing traverses a structure that is still being built
     t->ctx = ctx; t->n = n; t->nodes = nullptr; t->leaf_inst = nullptr; t->inst = nullptr; t->shade_inst = nullptr;
-    t->pool_nodes = nullptr; t->pool_nodes_f32 = nullptr; t->pool_tris = nullptr; t->pool_node_count = 0;
+    t->pool_nodes = nullptr; t->pool_nodes_f32 = nullptr; t->pool_tris = nullptr; t->pool_node_count = 0; t->n_root = 0;
     t->host_boxes.resize((size_t)n * 6); t->host_w2o.resize((size_t)n * 12);
     std::vector<PtDevInstance> di(n);
     t->host_o2w.resize((size_t)n * 12); t->host_custom.resize(n); t->host_prim_count.resize(n); t->shade_version = 0;
@@ -1323,7 +1329,9 @@ int pt_tlas_build(PtContext* ctx, const PtInstance* instances, uint32_t n, PtTla
             depth_blas = uniq[k]->wide_depth > depth_blas ? uniq[k]->wide_depth : depth_blas;
         }
         // a step pushes at most three references and an instance entry one
-        if (3 * t->wide_depth + 1 + 3 * depth_blas > 10 + PT_SPILL_STACK) {      // the shallowest LDS part of any traversal kernel is 10 entries
+        // (or, for a ray that starts with the instances of a small TLAS, all but one of them)
+        const uint32_t tlas_part = std::max(3 * t->wide_depth, n <= PT_ROOT_ITEMS_MAX ? n - 1 : 0u);
+        if (tlas_part + 1 + 3 * depth_blas > 10 + PT_SPILL_STACK) {      // the shallowest LDS part of any traversal kernel is 10 entries
             pt_set_error("pt_tlas_build: acceleration structure too deep for the traversal stack (%u + %u wide levels)", t->wide_depth, depth_blas);
             (void)hipFree(tlas_wide); return PT_ERROR_LIMIT;
         }
@@ -1357,6 +1365,11 @@ int pt_tlas_build(PtContext* ctx, const PtInstance* instances, uint32_t n, PtTla
         (void)hipFree(tlas_wide);
         if (e != hipSuccess) { pt_set_error("pt_tlas_build: %s", hipGetErrorString(e)); return PT_ERROR_HIP; }
         t->pool_node_count = total_nodes;
+        // over a few instances rays start with the instances themselves (pt_ray_start); PT_HIP_ROOT_ITEMS sets the
+        // largest such TLAS (0: every ray starts at the root node)
+        const char* ri = getenv("PT_HIP_ROOT_ITEMS");
+        const uint32_t most = ri ? (uint32_t)atoi(ri) : PT_ROOT_ITEMS_DEFAULT;
+        t->n_root = (n <= most && n <= PT_ROOT_ITEMS_MAX) ? (int)n : 0;
     }
     // instance records in the order of the TLAS leaves, so a leaf reference addresses its record
     // directly; the instance's own index (the tie-break key and what a hit reports) sits in q[5].y

@@ -129,6 +129,7 @@ __device__ __forceinline__ void pt_hit_update(PtHitRec& best, float t, uint32_t 
 struct PtTlasView {
     const float4* nodes;
     const float4* nodes_f32;       // the same nodes as PtWideF (128 bytes each)
+    int n_root;                    // instances a ray starts with (a TLAS of at most PT_ROOT_ITEMS_MAX, see pt_ray_start), or 0: it starts at node 0
     const float4* tris;
     const PtDevInstance* inst;     // in the order of the TLAS leaf slots
 };
@@ -197,6 +198,19 @@ typedef PtStackT<PT_LDS_STACK, 1> PtStack;
 // byte k of each word belongs to child k and a plane is fma(byte, step, origin).
 // Continues with the nearest child that the ray interval [tlo, hi] overlaps and pushes the others
 // so that nearer ones are popped first; returns the next item (a pop if nothing was hit).
+// What a ray starts with.  Over a handful of instances the box steps of the TLAS only order and cull what the
+// instance phase tests again with the exact boxes, at the price of full steps per ray: such a ray starts with the
+// instances themselves, in leaf-slot order (the closest hit does not depend on the order).  A TLAS leaf reference
+// is ~(slot << 3).
+template <typename STACK>
+__device__ __forceinline__ int pt_ray_start(const PtTlasView& tl, STACK& stk)
+{
+    stk.sp = 0;
+    if (tl.n_root == 0) return 0;
+    for (int k = tl.n_root - 1; k >= 1; --k) stk.push((int)~((uint32_t)k << 3));
+    return (int)~0u;
+}
+
 // F32 = false: the 64-byte node above.  F32 = true: the same node as 128 bytes with its planes as floats
 // (PtWideF: [lo.x hi.x lo.y hi.y lo.z hi.z] x four children, then the references).  The nearer plane vector of an
 // axis is the low one when 1/d > 0, and the ray's sign picks it by address, so the step needs neither the 24 byte
@@ -306,8 +320,7 @@ __device__ __forceinline__ void pt_closest_hit(const PtTlasView& tl, PtStack& st
     float delta = 0.0f;
     float tlo = tmin, thi = tmax;   // closed interval handed to box tests in the current space
     uint32_t cur_inst = PT_NO_INSTANCE;
-    stk.sp = 0;
-    int node = 0;
+    int node = pt_ray_start(tl, stk);
     for (;;) {
         while ((unsigned)node < (unsigned)PT_NODE_DONE)
             node = pt_wide_step<F32>(cur, F32 ? tl.nodes_f32 : tl.nodes, node, tlo, fminf(thi, best.t), stk);

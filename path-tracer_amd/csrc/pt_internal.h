@@ -66,12 +66,15 @@ struct PtBlas {
     float build_ms;
 };
 
+#define PT_ROOT_ITEMS_MAX 8          // largest TLAS whose rays may start with the instances instead of the root node
+
 struct PtTlas {
     PtContext* ctx;
     uint32_t n;
     uint32_t node_count;
     PtBvhNode* nodes;               // device: TLAS nodes alone (what pt_tlas_download returns)
     void* pool_nodes;               // device: 64-byte 4-wide quantised nodes, TLAS first then every distinct BLAS, references absolute
+    int n_root;                     // instances a ray starts with instead of the TLAS root (see pt_ray_start), or 0
     void* pool_nodes_f32;           // device: the same nodes as 128-byte PtWideF (float planes), what k_primary traverses
     float4* pool_tris;              // device: triangle records of every distinct BLAS, 3 float4 each
     uint32_t pool_node_count;

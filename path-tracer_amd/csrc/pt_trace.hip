@@ -759,6 +759,7 @@ PtTlasView view_of(const PtTlas* t)
 {
     PtTlasView v;
     v.nodes = (const float4*)t->pool_nodes; v.nodes_f32 = (const float4*)t->pool_nodes_f32; v.tris = t->pool_tris; v.inst = t->inst;
+    v.n_root = t->n_root;
     return v;
 }
 

@@ -168,8 +168,7 @@ __device__ __forceinline__ void pt_traverse_sched(const PtTlasView& tl, const Pt
                     ws[6 * PT_TRAVERSE_BLOCK] = cur.ix; ws[7 * PT_TRAVERSE_BLOCK] = cur.iy; ws[8 * PT_TRAVERSE_BLOCK] = cur.iz;
                     cur_inst = PT_NO_INSTANCE; tlo = tmin; thi = tmax;
                     best_t = tmax;
-                    stk.sp = 0;
-                    node = 0;
+                    node = pt_ray_start(tl, stk);
                 }
                 wcur += take;
                 idle = __ballot(node == PT_NODE_DONE);
