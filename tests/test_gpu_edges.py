@@ -161,3 +161,31 @@ def test_composite_scene_at_2160p(cornell, helmet, dragon):
         assert np.mean(np.abs(rows[:, 0] - rows[:, 2])) > 1e-3
     finally:
         r.close()
+
+
+@pytest.mark.parametrize("name,limit", [("cube", "0"), ("dragon", "0"), ("cornell", "8")])
+def test_rays_starting_with_the_instances_give_the_same_image(name, limit, request, monkeypatch):
+    """Under a TLAS of a few instances a ray starts with the instance leaves instead of the root node
+    (PT_HIP_ROOT_ITEMS: largest such TLAS, default 2).  The closest hit does not depend on that: a frame with the
+    other setting (root step for the one- and two-instance scenes, instance start for the eight of the Cornell box)
+    is the same bit for bit, for all three traversal schedules."""
+    from pt_amd import hip
+    scene = request.getfixturevalue(name)
+
+    def frame():
+        r = hip.Renderer(scene, 96, 64)
+        try:
+            r.render(spp=8, max_depth=6, frame=3)
+            img = r.accum_host().copy()
+            rays = int(r.stats()["rays"])
+        finally:
+            r.close()
+        return img, rays
+
+    for schedule in ("auto", "sched", "pair"):
+        monkeypatch.setenv("PT_HIP_TRAVERSAL", schedule)
+        monkeypatch.delenv("PT_HIP_ROOT_ITEMS", raising=False)
+        ref_img, ref_rays = frame()
+        monkeypatch.setenv("PT_HIP_ROOT_ITEMS", limit)
+        img, rays = frame()
+        assert rays == ref_rays and np.array_equal(img.view(np.uint32), ref_img.view(np.uint32)), schedule
