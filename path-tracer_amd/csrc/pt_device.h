@@ -241,7 +241,10 @@ __device__ __forceinline__ int pt_wide_step(const PtRaySpace& r, const float4* _
         const float ax = PT_FMA(nxv[k], r.ix, -r.oox), ay = PT_FMA(nyv[k], r.iy, -r.ooy), az = PT_FMA(nzv[k], r.iz, -r.ooz);
         const float bx = PT_FMA(fxv[k], r.ix, -r.oox), by = PT_FMA(fyv[k], r.iy, -r.ooy), bz = PT_FMA(fzv[k], r.iz, -r.ooz);
         const float a = fmaxf(fmaxf(ax, ay), az), b = fminf(fminf(bx, by), bz);
-        const bool hit = fmaxf(a, tlo) <= fminf(b, hi);      // an empty child is (+inf, -inf)
+        // An empty child is (+inf, -inf) and needs no test of its own (testing the reference as the 64-byte step
+        // does cost k_primary 6 %): a child is followed only if its entry distance compares below +inf, and an
+        // empty child's is +inf for a finite ray, NaN or an infinity for a ray that is not finite.
+        const bool hit = fmaxf(a, tlo) <= fminf(b, hi);
         tn[k] = hit ? a : inf;
     }
     } else {
