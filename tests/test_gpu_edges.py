@@ -189,3 +189,28 @@ def test_rays_starting_with_the_instances_give_the_same_image(name, limit, reque
         monkeypatch.setenv("PT_HIP_ROOT_ITEMS", limit)
         img, rays = frame()
         assert rays == ref_rays and np.array_equal(img.view(np.uint32), ref_img.view(np.uint32)), schedule
+
+
+@pytest.mark.parametrize("name", ["cube", "cornell"])
+def test_rays_and_cameras_that_are_not_finite_hit_nothing(name, request, monkeypatch):
+    """NaN and infinite origins or directions: every comparison of the box steps fails or yields NaN, which no
+    child's entry distance survives, so such a ray ends without a hit in every schedule, as in the oracle; a frame
+    from a camera of NaNs is traced to its end (bounce 0 walks the float-plane nodes, whose empty children are
+    (+inf, -inf) boxes) and holds the value of a first-bounce miss in every pixel."""
+    from pt_amd import hip
+    scene = request.getfixturevalue(name)
+    nan, inf = np.nan, np.inf
+    o = np.array([[nan, 0, 5], [0, 0, 5], [inf, 0, 5], [0, 0, 5], [0, 0, 5], [nan, nan, nan], [0, -inf, 0], [0, 0, 5]], np.float32)
+    d = np.array([[0, 0, -1], [nan, 0, -1], [0, 0, -1], [0, inf, -1], [nan, nan, nan], [0, 0, -1], [0, 1, 0], [-inf, inf, -inf]], np.float32)
+    for schedule in ("plain", "sched", "pair"):
+        ho, _ = _compare(scene, o, d, schedule, monkeypatch)
+        assert (ho["instance"] == 0xFFFFFFFF).all(), schedule
+    monkeypatch.setenv("PT_HIP_TRAVERSAL", "auto")
+    r = hip.Renderer(scene, 32, 16, camera=np.full(32, np.nan, np.float32))
+    try:
+        r.render(spp=4, max_depth=4, frame=0)
+        img = r.last_result()
+        assert int(r.stats()["rays"]) == 32 * 16 * 4          # every path ends at its first ray
+        assert np.array_equal(img, np.full_like(img, img[0, 0, 0])) and np.isfinite(img).all() and img[0, 0, 0] > 0
+    finally:
+        r.close()
