@@ -146,6 +146,33 @@ def cpu_baseline(scene, cam, width, height, spp, max_depth):
     }
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: runs this same command line under torch.distributed.run with N
+    ranks on this node (rendezvous on 127.0.0.1, a free port) as a child process; rank 0 of the child prints the
+    JSON line on the inherited stdout.  Returns the child's exit code."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # RCCL needs dmabuf IPC on these hosts
+    print("bench.py: starting " + " ".join(cmd[1:8]) + " ...", file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
+def rank_identity(torch, local_rank, rehearsal):
+    """What this rank runs on, for the line's `parallelism.ranks`: device index, name, PCI bus id."""
+    p = torch.cuda.get_device_properties(local_rank)
+    bus = None
+    if all(hasattr(p, k) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id")):
+        bus = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}"
+    return {"rank": int(os.environ.get("RANK", "0")), "device": local_rank, "name": p.name, "pci_bus_id": bus,
+            "uuid": str(getattr(p, "uuid", "")) or None, "pid": os.getpid(), "rehearsal_shared_device": bool(rehearsal)}
+
+
 def run_frames(renderer, accum_ptr, frames, spp, max_depth):
     from pt_amd import hip
     for f in frames:
@@ -184,6 +211,11 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the Cornell steps after the timed region (profiled runs)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # No launcher around us: start one rank per GPU as a child process and relay its line and exit code.
+        # This process has not touched the GPU (torch is not even imported yet) and never will.
+        raise SystemExit(launch_ranks(args.gpus))
+
     import torch
     import torch.distributed as dist
     from pt_amd import hip, sharding
@@ -195,8 +227,11 @@ def main():
     rehearsal = os.environ.get("PT_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local_rank = 0
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the line would not describe what ran")
+    visible = torch.cuda.device_count()
+    if not rehearsal and local_rank >= visible:
+        raise SystemExit(f"bench.py: rank {rank} wants device {local_rank} but {visible} device(s) are visible")
     torch.cuda.set_device(local_rank)
     backend = None
     if world > 1:
@@ -205,6 +240,19 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    identity = rank_identity(torch, local_rank, rehearsal)
+    ranks_seen = [identity]
+    if world > 1:
+        ranks_seen = [None] * world
+        dist.all_gather_object(ranks_seen, identity)
+        devices = {(r["pci_bus_id"], r["device"]) for r in ranks_seen}
+        if not rehearsal and len(devices) != world:
+            raise SystemExit(f"bench.py: {world} ranks share {len(devices)} device(s): {sorted(devices)}")
+    try:
+        rccl_version = ".".join(str(x) for x in torch.cuda.nccl.version())
+    except Exception:
+        rccl_version = None
 
     trace_t0 = time.perf_counter()
 
@@ -368,7 +416,8 @@ def main():
             "config": {"workload": f"{args.scene} {W}x{H}, {args.spp} spp per step, max depth {args.max_depth}"
                                    + (" (procedural stand-in for the missing DragonAttenuation.bin: 134,995 triangles, 2 instances)" if args.scene == "dragon" else ""),
                        "parallelism": {"scheme": f"spp-sharded x{world}, one sum all-reduce of the float image" if world > 1 else "single GPU",
-                                       "backend": backend, "world_size": world, "allreduce_ms": allreduce_ms,
+                                       "backend": backend, "world_size": world, "devices_visible": visible, "rccl_version": rccl_version,
+                                       "ranks": ranks_seen, "allreduce_ms": allreduce_ms,
                                        "allreduce_bytes": accum.numel() * 4 if world > 1 else 0,
                                        "steps_total": total_steps, "total_spp": total_steps * args.spp},
                        "frames_in_flight": fif, "triangles": scene.triangle_count(), "instances": len(scene.instances())},

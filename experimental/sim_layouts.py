@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Node visits and triangle tests per ray of the 4-wide layout (children sorted by distance, leaves of up to
 four triangles) and the 8-wide layout (octant order, one triangle per leaf child) on the same rays, simulated
-on the host with the builders' own per-node routines (libpt_wide_host.so).  usage: tools/sim_layouts.py [mesh 0|1] [rays]"""
+on the host with the builders' own per-node routines (make -C experimental).  usage: experimental/sim_layouts.py [mesh 0|1] [rays]"""
 import ctypes as C
 import os
 import sys
@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "path-tracer_amd"))
 from pt_amd import abi, procedural
 
-lib = C.CDLL(os.path.join(ROOT, "path-tracer_amd", "lib", "libpt_wide_host.so"))
+lib = C.CDLL(os.path.join(ROOT, "experimental", "_build", "libpt_layout_sim.so"))
 lib.pt_sah_build_host_c.restype = C.c_uint32
 lib.pt_wide_collapse_host.restype = C.c_uint32
 lib.pt_wide8_collapse_host.restype = C.c_uint32

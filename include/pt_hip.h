@@ -169,7 +169,10 @@ int pt_blas_wide_download(const PtBlas* blas, void* nodes64, uint32_t capacity, 
 int pt_blas_traversal_download(const PtBlas* blas, PtBvhNode* nodes, uint32_t capacity, uint32_t* leaf_prims, uint32_t* count_out);
 
 /* Replaces the TLAS build of source/top_level_acceleration_structure.cpp:19-113: n instance
- * records in host memory.  Blocks until built. */
+ * records in host memory.  Blocks until built.  The traversal pool of one TLAS (its own 4-wide nodes and
+ * those of every distinct BLAS under it) is addressed with 32-bit byte offsets into 128-byte records:
+ * PT_ERROR_LIMIT when it would hold PT_MAX_POOL_NODES nodes or more, or 2^28 triangles or more. */
+#define PT_MAX_POOL_NODES (1u << 25)
 int pt_tlas_build(PtContext* ctx, const PtInstance* instances, uint32_t n, PtTlas** out);
 int pt_tlas_destroy(PtTlas* tlas);   /* top_level_...cpp:16 */
 int pt_tlas_info(const PtTlas* tlas, PtAsInfo* out);

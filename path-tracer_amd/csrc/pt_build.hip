@@ -1322,16 +1322,23 @@ int pt_tlas_build(PtContext* ctx, const PtInstance* instances, uint32_t n, PtTla
         void* tlas_wide = nullptr;
         rc = pt_build_wide(ctx, t->nodes, t->node_count, &tlas_wide, &t->wide_count, &t->wide_depth);
         if (rc) return rc;
-        uint32_t total_nodes = t->wide_count, depth_blas = 0;
+        uint64_t total_nodes64 = t->wide_count;
+        uint32_t depth_blas = 0;
         std::vector<uint32_t> root_of(uniq.size());
         for (size_t k = 0; k < uniq.size(); ++k) {
-            root_of[k] = total_nodes; total_nodes += uniq[k]->wide_count;
+            root_of[k] = (uint32_t)total_nodes64; total_nodes64 += uniq[k]->wide_count;
             depth_blas = uniq[k]->wide_depth > depth_blas ? uniq[k]->wide_depth : depth_blas;
+            // the float-plane step addresses 128-byte nodes with a 32-bit byte offset (pt_wide_step<true>)
+            if (total_nodes64 >= PT_MAX_POOL_NODES) {
+                pt_set_error("pt_tlas_build: the traversal pool would hold %llu wide nodes, the limit is %u", (unsigned long long)total_nodes64, PT_MAX_POOL_NODES - 1u);
+                (void)hipFree(tlas_wide); return PT_ERROR_LIMIT;
+            }
         }
+        const uint32_t total_nodes = (uint32_t)total_nodes64;
         // a step pushes at most three references and an instance entry one
         // (or, for a ray that starts with the instances of a small TLAS, all but one of them)
         const uint32_t tlas_part = std::max(3 * t->wide_depth, n <= PT_ROOT_ITEMS_MAX ? n - 1 : 0u);
-        if (tlas_part + 1 + 3 * depth_blas > 10 + PT_SPILL_STACK) {      // the shallowest LDS part of any traversal kernel is 10 entries
+        if (tlas_part + 1 + 3 * depth_blas > PT_MIN_LDS_STACK + PT_SPILL_STACK) {      // the shallowest LDS part of any traversal kernel
             pt_set_error("pt_tlas_build: acceleration structure too deep for the traversal stack (%u + %u wide levels)", t->wide_depth, depth_blas);
             (void)hipFree(tlas_wide); return PT_ERROR_LIMIT;
         }

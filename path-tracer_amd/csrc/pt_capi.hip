@@ -67,19 +67,8 @@ int pt_lanes_resize(PtContext* c, int n)
     for (PtLane& l : c->lanes) lane_free(l);
     c->lanes.assign((size_t)n, PtLane());
     c->next_lane = 0; c->last_accumulate = nullptr;
-    // PT_HIP_LANE_PRIORITY=1 (an experiment, off by default): with exactly two streams the first is created at the
-    // highest priority and the second at the lowest, so that the later frame fills what the earlier one leaves idle
-    // instead of sharing the GPU with it evenly.  Measured on the dragon step: 110.7 ms against 112.8 ms with two
-    // plain streams and 113.2 ms with one.  Not the default: with three streams and a frame in several chunks,
-    // whose image updates wait for one another across the streams, a run with prioritised streams never finished.
-    int prio_lo = 0, prio_hi = 0;
-    const char* pe = getenv("PT_HIP_LANE_PRIORITY");
-    const bool prioritised = pe && atoi(pe) == 1 && n == 2;
-    if (prioritised) PT_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-    int k = 0;
     for (PtLane& l : c->lanes) {
-        if (prioritised) PT_HIP_CHECK(hipStreamCreateWithPriority(&l.stream, hipStreamNonBlocking, k++ == 0 ? prio_hi : prio_lo));
-        else PT_HIP_CHECK(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
+        PT_HIP_CHECK(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
         PT_HIP_CHECK(hipEventCreateWithFlags(&l.done, hipEventDisableTiming));
         PT_HIP_CHECK(hipEventCreateWithFlags(&l.accumulated, hipEventDisableTiming));
     }
@@ -114,7 +103,12 @@ int pt_ctx_create(int device_id, void* hip_stream, PtContext** out)
     PtContext* c = new PtContext();
     c->device = device_id;
     c->num_cus = prop.multiProcessorCount;
-    if (const char* e = getenv("PT_HIP_TRAVERSAL")) c->traversal_mode = strcmp(e, "plain") == 0 ? 0 : (strcmp(e, "sched") == 0 ? 1 : (strcmp(e, "pair") == 0 ? 3 : 2));
+    if (const char* e = getenv("PT_HIP_TRAVERSAL")) {
+        c->traversal_mode = strcmp(e, "plain") == 0 ? 0 : (strcmp(e, "sched") == 0 ? 1 : 2);
+#ifdef PT_EXPERIMENTAL
+        if (strcmp(e, "pair") == 0) c->traversal_mode = 3;
+#endif
+    }
     if (const char* e = getenv("PT_HIP_SCHED_MIN_RAYS")) c->sched_min_rays = (uint32_t)strtoul(e, nullptr, 10);
     if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
     else {

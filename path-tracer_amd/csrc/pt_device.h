@@ -224,6 +224,7 @@ __device__ __forceinline__ int pt_wide_step(const PtRaySpace& r, const float4* _
     float tn[4]; int ref[4];
     const float inf = __builtin_inff();
     if constexpr (F32) {
+    static_assert(((unsigned long long)PT_MAX_POOL_NODES << 7) <= (1ull << 32), "pool nodes are addressed with 32-bit byte offsets");
     const uint32_t base = (uint32_t)node << 7;
     const uint32_t sx = (__float_as_uint(r.ix) >> 27) & 16u, sy = (__float_as_uint(r.iy) >> 27) & 16u, sz = (__float_as_uint(r.iz) >> 27) & 16u;
     const char* pool = (const char*)nodes;

@@ -135,6 +135,12 @@ struct PtWorkspace {                   // shared by all lanes
 #ifndef PT_SPILL_STACK
 #define PT_SPILL_STACK 112
 #endif
+// entries the shallowest LDS stack of any traversal kernel holds (the experimental two-rays-per-lane kernel keeps 10 per ray)
+#ifdef PT_EXPERIMENTAL
+#define PT_MIN_LDS_STACK (PT_LDS_STACK < 10 ? PT_LDS_STACK : 10)
+#else
+#define PT_MIN_LDS_STACK PT_LDS_STACK
+#endif
 
 struct PtContext {
     int device = 0;
@@ -142,7 +148,7 @@ struct PtContext {
     bool own_stream = false;
     int num_cus = 0;
     uint64_t max_paths = 1ull << 27;
-    int traversal_mode = 2;   // 0: one batch of 64 rays per wave at a time; 1: wave-scheduled with ray replacement; 2: chosen per level; 3: wave-scheduled with two rays per lane (PT_HIP_TRAVERSAL=plain|sched|auto|pair)
+    int traversal_mode = 2;   // 0: one batch of 64 rays per wave at a time; 1: wave-scheduled with ray replacement; 2: chosen per level; (PT_HIP_TRAVERSAL=plain|sched|auto); 3, builds with PT_EXPERIMENTAL only: wave-scheduled with two rays per lane
     uint32_t sched_min_rays = 1200000;   // mode 2: levels with at least this many rays are wave-scheduled (PT_HIP_SCHED_MIN_RAYS)
     // tables
     PtMaterial* materials = nullptr; uint32_t n_materials = 0;
@@ -169,6 +175,8 @@ struct PtContext {
     uint32_t* mailbox_dev = nullptr;           // ... as the device addresses them
     std::vector<uint32_t> ev_depth;            // depth of each recorded pair
     uint64_t stats_mark[PT_MAX_DEPTH] = {};    // rays_per_depth at the last pt_trace_profile
+    unsigned char* na_scratch = nullptr;       // pt_intersect_noalloc: device address of this GPU's fixed workspace ...
+    int na_blocks = 0;                         // ... and the grid of its traversal launch
 };
 
 // pt_capi.hip: frames in flight

@@ -25,9 +25,12 @@
 // round trip.  Survivors of shard s go to shard s of the next queue, which therefore never overflows.
 #include "pt_device.h"
 #include "pt_traverse_sched.h"
-#include "pt_traverse_pair.h"
+#ifdef PT_EXPERIMENTAL
+#include "pt_traverse_pair.h"     // experimental/: two rays per lane, measured slower (make EXPERIMENTAL=1)
+#endif
 #include <string.h>
 #include <algorithm>
+#include <mutex>
 
 namespace {
 
@@ -206,6 +209,7 @@ k_intersect(PtTlasView tl, uint32_t* __restrict__ counters, uint32_t depth, uint
     });
 }
 
+#ifdef PT_EXPERIMENTAL
 // traceRayEXT for every ray of one bounce with two rays per lane (pt_traverse_pair.h): four waves per SIMD,
 // 40 KB of LDS per block.
 #ifndef PT_PAIR_WAVES
@@ -223,6 +227,7 @@ k_intersect_pair(PtTlasView tl, uint32_t* __restrict__ counters, uint32_t depth,
     Q.count_base = ctr_index(CTR_COUNT, depth, 0); Q.work_base = ctr_index(CTR_WORK_INTERSECT, depth, 0);
     pt_traverse_pair<BY_ID>(tl, Q, (pt_lds_int*)&s_pair[0][threadIdx.x], spill, q0, q1, tmin, tmax, hits, t_out);
 }
+#endif
 
 // rays given as packed float3 arrays (pt_intersect entry point): repack into the float4 streams
 __global__ void k_pack_rays(uint32_t n, uint32_t shard_cap, const float* __restrict__ o, const float* __restrict__ d,
@@ -751,7 +756,7 @@ uint32_t sched_threshold(const PtContext* ctx, uint32_t depth)
 {
     if (ctx->traversal_mode == 0) return 0xFFFFFFFFu;        // plain everywhere
     if (ctx->traversal_mode == 1) return 0u;                 // scheduled everywhere
-    if (ctx->traversal_mode == 3) return ctx->sched_min_rays; // (the two-rays-per-lane kernel has its own launch; this is for entry points that do not use it)
+    if (ctx->traversal_mode == 3) return ctx->sched_min_rays; // (experimental two-rays-per-lane kernel: has its own launch; this is for entry points that do not use it)
     return depth == 0 ? 0xFFFFFFFFu : ctx->sched_min_rays;   // primary rays are coherent
 }
 
@@ -782,18 +787,23 @@ static __device__ __align__(256) unsigned char scratch[kNaBytes];
 constexpr int kNaMaxDevices = 64;
 static unsigned char* g_scratch_ptr[kNaMaxDevices];    // device address of `scratch` on each GPU (the array's name is only a host-side stand-in)
 static int g_na_blocks[kNaMaxDevices];
+static std::mutex g_na_mutex;                          // contexts may be created from several threads: both tables are filled under it
 
 // Called by pt_ctx_create with the context's device current: looks up this GPU's copy of the array
 // once and the grid of the traversal kernel, so that the entry point itself asks the runtime for nothing.
 int pt_noalloc_setup(PtContext* ctx)
 {
     PT_REQUIRE(ctx->device >= 0 && ctx->device < kNaMaxDevices, "device index beyond the table of scratch addresses");
-    if (g_scratch_ptr[ctx->device]) return PT_OK;
-    unsigned char* ptr = nullptr;
-    PT_HIP_CHECK(hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch)));
-    PT_REQUIRE(ptr != nullptr, "hipGetSymbolAddress returned a null address");
-    g_na_blocks[ctx->device] = std::min(kNaBlocks, persistent_blocks(ctx, (const void*)k_intersect<true>));
-    g_scratch_ptr[ctx->device] = ptr;
+    std::lock_guard<std::mutex> lock(g_na_mutex);
+    if (!g_scratch_ptr[ctx->device]) {
+        unsigned char* ptr = nullptr;
+        PT_HIP_CHECK(hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch)));
+        PT_REQUIRE(ptr != nullptr, "hipGetSymbolAddress returned a null address");
+        g_na_blocks[ctx->device] = std::min(kNaBlocks, persistent_blocks(ctx, (const void*)k_intersect<true>));
+        g_scratch_ptr[ctx->device] = ptr;
+    }
+    // the context keeps its own copy: the entry point reads no table another thread may be filling
+    ctx->na_scratch = g_scratch_ptr[ctx->device]; ctx->na_blocks = g_na_blocks[ctx->device];
     return PT_OK;
 }
 
@@ -807,8 +817,8 @@ extern "C" int pt_intersect_noalloc(PtContext* ctx, const PtTlas* tlas, uint32_t
         return PT_ERROR_LIMIT;
     }
     if (n == 0) return PT_OK;
-    unsigned char* base = g_scratch_ptr[ctx->device];
-    PT_REQUIRE(base != nullptr, "the fixed workspace was not set up for this device");
+    unsigned char* base = ctx->na_scratch;
+    PT_REQUIRE(base != nullptr && ctx->na_blocks > 0, "the fixed workspace was not set up for this device");
     PT_HIP_CHECK(hipSetDevice(ctx->device));
     float4* q0 = (float4*)base;
     float4* q1 = (float4*)(base + kNaStream);
@@ -823,7 +833,7 @@ extern "C" int pt_intersect_noalloc(PtContext* ctx, const PtTlas* tlas, uint32_t
     k_pack_rays<<<(n + kBlock - 1) / kBlock, kBlock, 0, st>>>(n, cap, origins_dev, dirs_dev, q0, q1, counters);
     PtTlasView tv = view_of(tlas);
     const uint32_t thr = ctx->traversal_mode == 0 ? 0xFFFFFFFFu : (ctx->traversal_mode == 1 ? 0u : ctx->sched_min_rays);   // mode 3 (two rays per lane) needs twice the stack slices: not used here
-    k_intersect<true><<<g_na_blocks[ctx->device], kBlock, 0, st>>>(tv, counters, 0, cap, q0, q1, tmin, tmax, hits_dev, t_dev, spill, thr);
+    k_intersect<true><<<ctx->na_blocks, kBlock, 0, st>>>(tv, counters, 0, cap, q0, q1, tmin, tmax, hits_dev, t_dev, spill, thr);
     PT_HIP_CHECK(hipGetLastError());
     return PT_OK;
 }
@@ -848,11 +858,14 @@ int pt_intersect(PtContext* ctx, const PtTlas* tlas, uint32_t n, const float* or
     k_pack_rays<<<(n + kBlock - 1) / kBlock, kBlock, 0, st>>>(n, w.shard_cap, origins_dev, dirs_dev, w.q[0][0], w.q[0][1], w.counters);
     {
         // caller-supplied rays are treated as incoherent: scheduled above the threshold
+#ifdef PT_EXPERIMENTAL
         if (ctx->traversal_mode == 3) {
             const int blocks = std::min(persistent_blocks(ctx, (const void*)k_intersect_pair<true>), ctx->num_cus * 4);
             k_intersect_pair<true><<<blocks, kBlock, 0, st>>>(view_of(tlas), w.counters, 0, w.shard_cap, w.q[0][0], w.q[0][1],
                                                               tmin, tmax, hits_dev, t_dev, w.spill);
-        } else {
+        } else
+#endif
+        {
             const int blocks = persistent_blocks(ctx, (const void*)k_intersect<true>);
             k_intersect<true><<<blocks, kBlock, 0, st>>>(view_of(tlas), w.counters, 0, w.shard_cap, w.q[0][0], w.q[0][1],
                                                          tmin, tmax, hits_dev, t_dev, w.spill, sched_threshold(ctx, 1));
@@ -885,7 +898,9 @@ int pt_trace(PtContext* ctx, const PtTlas* tlas, const float camera[32], uint32_
     memcpy(primary.camera.m, camera, sizeof primary.camera.m);
     primary.spp = spp; primary.W = width; primary.H = height; primary.frame = frame; primary.seed_mode = seed_mode;
     const int blocks_i = persistent_blocks(ctx, (const void*)k_intersect<false>);
+#ifdef PT_EXPERIMENTAL
     const int blocks_pair = std::min(persistent_blocks(ctx, (const void*)k_intersect_pair<false>), ctx->num_cus * 4);   // two stack slices per thread
+#endif
     // whole multiples of kShards waves (four waves per block): the passes that deal batches by index need them
     const int blocks_p = std::max(16, persistent_blocks(ctx, (const void*)k_primary) / 16 * 16);
     const int blocks_s = std::max(16, persistent_blocks(ctx, (const void*)k_shade) * PT_SHADE_GRID / 16 * 16);
@@ -927,10 +942,12 @@ int pt_trace(PtContext* ctx, const PtTlas* tlas, const float camera[32], uint32_
                 k_primary<<<blocks_p, kBlock, 0, st>>>(tv, sa, 0.001f, 10000.0f, w.spill);
                 if (ev_stop) PT_HIP_CHECK(hipEventRecord(ev_stop, st));
             } else {
+#ifdef PT_EXPERIMENTAL
                 if (ctx->traversal_mode == 3)
                     k_intersect_pair<false><<<blocks_pair, kBlock, 0, st>>>(tv, w.counters, d, w.shard_cap, w.q[a][0], w.q[a][1],
                                                                             0.001f, 10000.0f, w.hits, nullptr, w.spill);
                 else
+#endif
                     k_intersect<false><<<blocks_i, kBlock, 0, st>>>(tv, w.counters, d, w.shard_cap, w.q[a][0], w.q[a][1],
                                                                     0.001f, 10000.0f, w.hits, nullptr, w.spill, sched_threshold(ctx, d));
                 if (ev_stop) PT_HIP_CHECK(hipEventRecord(ev_stop, st));

@@ -46,7 +46,7 @@ def _compare(scene, o, d, schedule, monkeypatch):
         r.close()
 
 
-@pytest.mark.parametrize("schedule", ["plain", "sched", "pair"])
+@pytest.mark.parametrize("schedule", ["plain", "sched"])
 def test_degenerate_rays(cube, schedule, monkeypatch):
     """Zero direction components (the slab reciprocal is clamped), a zero direction, rays through
     vertices and along edges, origins on faces and inside, and directions of tiny or huge length."""
@@ -77,7 +77,7 @@ def test_degenerate_rays(cube, schedule, monkeypatch):
     assert (ho["instance"] != 0xFFFFFFFF).sum() > 500
 
 
-@pytest.mark.parametrize("schedule", ["plain", "sched", "pair"])
+@pytest.mark.parametrize("schedule", ["plain", "sched"])
 def test_single_triangle_and_degenerate_triangles(schedule, monkeypatch):
     """A one-triangle BLAS (no inner node), then a mesh mixing proper, zero-area and repeated
     triangles (all keys equal, ties in the radix tree), instanced three times with scale and shear."""
@@ -182,7 +182,7 @@ def test_rays_starting_with_the_instances_give_the_same_image(name, limit, reque
             r.close()
         return img, rays
 
-    for schedule in ("auto", "sched", "pair"):
+    for schedule in ("auto", "sched"):
         monkeypatch.setenv("PT_HIP_TRAVERSAL", schedule)
         monkeypatch.delenv("PT_HIP_ROOT_ITEMS", raising=False)
         ref_img, ref_rays = frame()
@@ -202,7 +202,7 @@ def test_rays_and_cameras_that_are_not_finite_hit_nothing(name, request, monkeyp
     nan, inf = np.nan, np.inf
     o = np.array([[nan, 0, 5], [0, 0, 5], [inf, 0, 5], [0, 0, 5], [0, 0, 5], [nan, nan, nan], [0, -inf, 0], [0, 0, 5]], np.float32)
     d = np.array([[0, 0, -1], [nan, 0, -1], [0, 0, -1], [0, inf, -1], [nan, nan, nan], [0, 0, -1], [0, 1, 0], [-inf, inf, -inf]], np.float32)
-    for schedule in ("plain", "sched", "pair"):
+    for schedule in ("plain", "sched"):
         ho, _ = _compare(scene, o, d, schedule, monkeypatch)
         assert (ho["instance"] == 0xFFFFFFFF).all(), schedule
     monkeypatch.setenv("PT_HIP_TRAVERSAL", "auto")

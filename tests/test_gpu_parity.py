@@ -71,7 +71,7 @@ def test_bvh_topology_bit_exact(name, request):
         r.close()
 
 
-@pytest.mark.parametrize("schedule", ["plain", "sched", "pair"])
+@pytest.mark.parametrize("schedule", ["plain", "sched"])
 @pytest.mark.parametrize("name,n", [("cornell", 200000), ("cube", 100000), ("soup", 100000), ("dragon", 100000)])
 def test_intersect_hit_ids_bit_exact(name, n, schedule, request, monkeypatch):
     monkeypatch.setenv("PT_HIP_TRAVERSAL", schedule)   # both traversal schedules, whatever the level size
@@ -94,7 +94,7 @@ def test_intersect_hit_ids_bit_exact(name, n, schedule, request, monkeypatch):
         r.close()
 
 
-@pytest.mark.parametrize("schedule", ["plain", "sched", "pair"])
+@pytest.mark.parametrize("schedule", ["plain", "sched"])
 @pytest.mark.parametrize("name,w,h,spp", [("cornell", 128, 128, 16), ("cube", 96, 64, 8), ("dragon", 160, 90, 4), ("soup", 64, 64, 4),
                                           # the reference's 25 samples per frame on an odd image (batches straddle pixels, the last
                                           # batch is partial), one sample, and more samples than a batch holds
@@ -144,7 +144,7 @@ def test_texture_sizes_that_are_not_powers_of_two(tw, th, cube):
 HELMET_CAMERA = dict(eye=(0.15, 0.1, 0.75), center=(0.0, 0.0, 0.0), fov_deg=50.0)
 
 
-@pytest.mark.parametrize("schedule", ["plain", "sched", "pair"])
+@pytest.mark.parametrize("schedule", ["plain", "sched"])
 def test_helmet_textured_frame_bit_exact(helmet, schedule, monkeypatch):
     """BASELINE config 3's scene (FlightHelmet: 5 instances, 94,722 triangles, four base-colour
     textures sampled through the mesh's own UVs) with a camera that frames it: hit records of the
@@ -218,7 +218,7 @@ def test_exact_ties_between_instances(stacked, cornell):
         r.close()
 
 
-@pytest.mark.parametrize("schedule", ["plain", "sched", "auto", "pair"])
+@pytest.mark.parametrize("schedule", ["plain", "sched", "auto"])
 def test_cfg1_golden_full_size(cornell, schedule, monkeypatch):
     """BASELINE config 1 in full (Cornell 512x512, 16 spp, frame 0) against the committed oracle
     outputs: SHA-256 of the whole float image, the radiance crop, the ray count and the bounce-0 ids."""

@@ -33,7 +33,7 @@ def _noalloc(r, o, d, tmin=0.001, tmax=10000.0):
     return hits, t
 
 
-@pytest.mark.parametrize("schedule", ["plain", "sched", "pair"])
+@pytest.mark.parametrize("schedule", ["plain", "sched"])
 def test_noalloc_matches_pt_intersect_on_two_calls(schedule, dragon, monkeypatch):
     monkeypatch.setenv("PT_HIP_TRAVERSAL", schedule)
     from pt_amd import hip
