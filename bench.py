@@ -207,6 +207,10 @@ def main():
                          "computed from the timed region's overlapping launches and says so)")
     ap.add_argument("--cpu-spp", type=int, default=16, help="samples per pixel of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--share-primary", action="store_true",
+                    help="trace bounce 0 once per pixel and share its hit among the pixel's samples (pt_ctx_set_share_primary: identical "
+                         "images, fewer rays traversed).  Off by default: the headline counts one traceRayEXT per sample and bounce, as the "
+                         "reference executes them; the default line reports the option's effect under `share_primary`")
     ap.add_argument("--secondary", action="store_true", help="accepted for older command lines; the Cornell measurement is on by default")
     ap.add_argument("--no-secondary", action="store_true", help="skip the Cornell steps after the timed region (profiled runs)")
     args = ap.parse_args()
@@ -273,6 +277,7 @@ def main():
     r = hip.Renderer(scene, W, H, device=local_rank, stream=stream, camera=cam)
     torch.cuda.synchronize()
     setup_s = time.perf_counter() - t0
+    r.ctx.set_share_primary(args.share_primary)
     phase("renderer built")
     build_ms = sum(float(b.info()["build_ms"]) for b in r.blases) + float(r.tlas.info()["build_ms"])
     accum = torch.zeros(H * W * 4, dtype=torch.float32, device="cuda")
@@ -420,7 +425,8 @@ def main():
                                        "ranks": ranks_seen, "allreduce_ms": allreduce_ms,
                                        "allreduce_bytes": accum.numel() * 4 if world > 1 else 0,
                                        "steps_total": total_steps, "total_spp": total_steps * args.spp},
-                       "frames_in_flight": fif, "triangles": scene.triangle_count(), "instances": len(scene.instances())},
+                       "frames_in_flight": fif, "triangles": scene.triangle_count(), "instances": len(scene.instances()),
+                       "share_primary": bool(args.share_primary)},
             "paths_per_s": paths / elapsed, "rays_per_path": rays / paths, "time_to_image_s": elapsed,
             "frames_accumulated": frames_seen, "bvh_build_ms": build_ms, "setup_s": setup_s,
         }
@@ -451,6 +457,23 @@ def main():
         out["roofline"] = make_roofline(i_n, i_ms, i_rays, n_simds, pmc_record(wkey), compulsory, survey, roof_fif, per_kernel)
         out["roofline"]["durations_from"] = ("the timed region" if prof_roof is prof else "three steps after the timed region") + \
                                             f", {roof_fif} frame(s) in flight" + ("" if roof_fif == 1 else ": launches overlap, durations are stretched")
+        if world == 1 and not args.no_secondary and not args.share_primary:
+            # the same steps with bounce 0 traversed once per pixel (same images; fewer rays, so paths/s is the figure to compare)
+            r.ctx.set_frames_in_flight(fif)
+            r.ctx.set_share_primary(True)
+            run_frames(r, accum.data_ptr(), range(4_000_000, 4_000_000 + max(2, fif)), args.spp, args.max_depth)
+            r.ctx.sync()
+            r.reset_stats()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            run_frames(r, accum.data_ptr(), range(4_100_000, 4_100_003), args.spp, args.max_depth)
+            r.ctx.sync()
+            dt = time.perf_counter() - t1
+            s3 = r.stats()
+            out["share_primary"] = {"ms_per_step": 1e3 * dt / 3, "steps": 3, "paths_per_s": int(s3["paths"]) / dt, "rays_traversed_per_s": int(s3["rays"]) / dt,
+                                    "time_to_image_s_at_equal_spp": dt / 3 * args.steps, "speedup_in_paths_per_s": (int(s3["paths"]) / dt) / (paths / elapsed),
+                                    "note": "pt_ctx_set_share_primary(1): bounce 0 traversed once per pixel, images bit-identical; not part of `value`"}
+            r.ctx.set_share_primary(False)
         if world == 1 and not args.no_secondary and args.scene == "dragon":
             # the metric's other scene, after the timed region
             r.close()

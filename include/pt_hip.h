@@ -218,6 +218,14 @@ int pt_trace(PtContext* ctx, const PtTlas* tlas, const float camera[32], uint32_
              uint32_t frame, uint32_t samples_per_frame, uint32_t max_depth,
              uint32_t seed_mode, uint32_t accum_mode, void* accum_dev);
 
+/* Option of pt_trace, off by default.  The reference's primary ray does not depend on the sample
+ * (shaders/ray_gen.rgen:21-27: no jitter; the sample loop :38-47 starts every path with the same origin and
+ * direction), so the traceRayEXT of bounce 0 (:54-65) returns the same hit for all samples of a pixel.  With the
+ * option on it is executed once per pixel and its hit is handed to the pixel's samples, which are shaded one by
+ * one as before: images are bit-identical, bounce 0 costs one traversal per pixel instead of one per sample, and
+ * pt_trace_stats counts the rays that were traversed (rays_per_depth[0] = pixels, not paths). */
+int pt_ctx_set_share_primary(PtContext* ctx, int enabled);
+
 /* Per-pixel value of `result` (shaders/ray_gen.rgen:74) of the last pt_trace: width*height*3
  * floats to host memory.  Synchronous; for tests. */
 int pt_trace_last_result(PtContext* ctx, float* result_host);

@@ -164,6 +164,7 @@ struct PtContext {
     PtLane* last_accumulate = nullptr;         // lane whose k_accumulate every later one has to follow
     hipEvent_t start_ev = nullptr;             // marks the caller's stream at the start of a unit of work
     uint32_t last_w = 0, last_h = 0;
+    bool share_primary = false;                // bounce 0 is traced once per pixel and shared by the pixel's samples (pt_ctx_set_share_primary)
     // intersect-kernel timing (pt_ctx_set_profiling)
     bool profiling = false;
     std::vector<hipEvent_t> ev_pool;           // pairs: start, stop

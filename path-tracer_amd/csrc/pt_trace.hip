@@ -531,25 +531,55 @@ k_shade(PtShadeArgs A, const PtHit* __restrict__ hits)
 #ifndef PT_PRIMARY_F32
 #define PT_PRIMARY_F32 true        // the 64 lanes of a wave hold one pixel's samples and walk the same nodes: float planes, loads are broadcasts
 #endif
+// SHARED: the reference traces one and the same primary ray for every sample of a pixel (ray_gen.rgen:21-27 has no
+// jitter, the sample loop :38-47 starts each path with it), so its closest hit can be found once per pixel
+// (k_primary_hits) and handed to the pixel's samples, which are shaded as before.  An option of the context, off
+// by default: a ray of the rays/s metric is one traceRayEXT of the reference, and with the option on bounce 0
+// executes (and counts) one per pixel instead of one per sample.
+template <bool SHARED>
 __global__ void __launch_bounds__(kBlock, PT_PRIMARY_WAVES)
-k_primary(PtTlasView tl, PtShadeArgs A, float tmin, float tmax, int* __restrict__ spill)
+k_primary(PtTlasView tl, PtShadeArgs A, float tmin, float tmax, int* __restrict__ spill, const PtHit* __restrict__ pixel_hits)
 {
-    __shared__ int s_stack[PT_LDS_STACK][kBlock];
+    __shared__ int s_stack[SHARED ? 1 : PT_LDS_STACK][kBlock];
     PtStack stk;
     stk.lds = (pt_lds_int*)&s_stack[0][threadIdx.x];
     stk.spill_base = spill;
     for_each_batch<PT_PRIMARY_STATIC>(A.counters, CTR_WORK_INTERSECT, 0, A.shard_cap, [&](uint32_t i, bool valid, uint32_t shard) {
         PtHit h; h.instance = 0xFFFFFFFFu; h.primitive = 0u; h.u = h.v = 0.0f;
         if (valid) {
-            float ox, oy, oz, dx, dy, dz;
-            pt_primary_ray(A.primary, path_of_slot(i, shard, A.shard_cap), ox, oy, oz, dx, dy, dz);
-            PtHitRec r;
-            pt_closest_hit<PT_PRIMARY_F32>(tl, stk, ox, oy, oz, dx, dy, dz, tmin, tmax, r);
-            h.instance = r.inst; h.primitive = r.prim; h.u = r.u; h.v = r.v;
+            const uint32_t q = path_of_slot(i, shard, A.shard_cap);
+            if constexpr (SHARED) {
+                h = pixel_hits[q / A.primary.spp];     // the lanes of a wave hold a pixel's samples: a broadcast
+            } else {
+                float ox, oy, oz, dx, dy, dz;
+                pt_primary_ray(A.primary, q, ox, oy, oz, dx, dy, dz);
+                PtHitRec r;
+                pt_closest_hit<PT_PRIMARY_F32>(tl, stk, ox, oy, oz, dx, dy, dz, tmin, tmax, r);
+                h.instance = r.inst; h.primitive = r.prim; h.u = r.u; h.v = r.v;
+            }
         }
         shade_batch<true>(A, A.shade_inst, A.o0, A.o1, A.o2, A.o3, A.path_result, i, valid, shard, h,
                           make_float4(1.0f, 1.0f, 1.0f, 0.0f), make_float4(0.0f, 0.0f, 0.0f, 0.0f));
     });
+}
+
+// The closest hit of the primary ray of every pixel of a chunk (the shared-primary option): one ray per lane,
+// neighbouring lanes neighbouring pixels, a grid-stride loop over the chunk (the stack slices are per resident thread).
+__global__ void __launch_bounds__(kBlock, PT_PRIMARY_WAVES)
+k_primary_hits(PtTlasView tl, PtPrimaryArg P, uint32_t n_pixels, float tmin, float tmax, int* __restrict__ spill, PtHit* __restrict__ pixel_hits)
+{
+    __shared__ int s_stack[PT_LDS_STACK][kBlock];
+    PtStack stk;
+    stk.lds = (pt_lds_int*)&s_stack[0][threadIdx.x];
+    stk.spill_base = spill;
+    for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < n_pixels; p += gridDim.x * kBlock) {
+        float ox, oy, oz, dx, dy, dz;
+        pt_primary_ray(P, p * P.spp, ox, oy, oz, dx, dy, dz);
+        PtHitRec r;
+        pt_closest_hit<false>(tl, stk, ox, oy, oz, dx, dy, dz, tmin, tmax, r);
+        PtHit h; h.instance = r.inst; h.primitive = r.prim; h.u = r.u; h.v = r.v;
+        pixel_hits[p] = h;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -609,11 +639,13 @@ k_accumulate(uint32_t n_pixels, uint32_t pixel0, uint32_t spp, uint32_t frame, u
     }
 }
 
-__global__ void k_stats(const uint32_t* __restrict__ counters, uint32_t max_depth, uint32_t n_paths, uint64_t* __restrict__ stats)
+// primary_rays: rays traced at bounce 0 (one per path, or one per pixel with the shared-primary option)
+__global__ void k_stats(const uint32_t* __restrict__ counters, uint32_t max_depth, uint32_t n_paths, uint32_t primary_rays, uint64_t* __restrict__ stats)
 {
     const uint32_t d = blockIdx.x, s = threadIdx.x;   // one wave per depth, one lane per shard
     uint32_t c = (d < max_depth && s < kShards) ? counters[ctr_index(CTR_COUNT, d, s)] : 0u;
     for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+    if (d == 0) c = primary_rays;
     // lanes run this concurrently
     if (s == 0 && d < max_depth) atomicAdd((unsigned long long*)&stats[d], (unsigned long long)c);
     if (s == 0 && d == 0) atomicAdd((unsigned long long*)&stats[PT_MAX_DEPTH], (unsigned long long)n_paths);
@@ -902,7 +934,9 @@ int pt_trace(PtContext* ctx, const PtTlas* tlas, const float camera[32], uint32_
     const int blocks_pair = std::min(persistent_blocks(ctx, (const void*)k_intersect_pair<false>), ctx->num_cus * 4);   // two stack slices per thread
 #endif
     // whole multiples of kShards waves (four waves per block): the passes that deal batches by index need them
-    const int blocks_p = std::max(16, persistent_blocks(ctx, (const void*)k_primary) / 16 * 16);
+    const bool shared = ctx->share_primary;
+    const int blocks_p = std::max(16, persistent_blocks(ctx, shared ? (const void*)k_primary<true> : (const void*)k_primary<false>) / 16 * 16);
+    const int blocks_ph = persistent_blocks(ctx, (const void*)k_primary_hits);
     const int blocks_s = std::max(16, persistent_blocks(ctx, (const void*)k_shade) * PT_SHADE_GRID / 16 * 16);
     // Every chunk of the frame goes to the next lane and is left in flight there; only the
     // read-modify-write of the image is chained, in submission order.
@@ -939,7 +973,13 @@ int pt_trace(PtContext* ctx, const PtTlas* tlas, const float camera[32], uint32_
             sa.path_result = w.path_result; sa.primary = primary;
             if (d == 0) {
                 // the timed interval of bounce 0 holds its shading as well
-                k_primary<<<blocks_p, kBlock, 0, st>>>(tv, sa, 0.001f, 10000.0f, w.spill);
+                if (shared) {
+                    // the chunk's pixel hits sit at the start of the hit records, which no kernel touches before bounce 1
+                    k_primary_hits<<<std::min(blocks_ph, (int)((np + kBlock - 1) / kBlock)), kBlock, 0, st>>>(tv, primary, np, 0.001f, 10000.0f, w.spill, w.hits);
+                    k_primary<true><<<blocks_p, kBlock, 0, st>>>(tv, sa, 0.001f, 10000.0f, w.spill, w.hits);
+                } else {
+                    k_primary<false><<<blocks_p, kBlock, 0, st>>>(tv, sa, 0.001f, 10000.0f, w.spill, nullptr);
+                }
                 if (ev_stop) PT_HIP_CHECK(hipEventRecord(ev_stop, st));
             } else {
 #ifdef PT_EXPERIMENTAL
@@ -959,7 +999,7 @@ int pt_trace(PtContext* ctx, const PtTlas* tlas, const float camera[32], uint32_
         k_accumulate<<<(np + kBlock - 1) / kBlock, kBlock, 0, st>>>(np, (uint32_t)p0, spp, frame, accum_mode, w.path_result, ctx->ws.frame_result, accum_dev);
         PT_HIP_CHECK(hipEventRecord(w.accumulated, st));
         ctx->last_accumulate = lane;
-        k_stats<<<max_depth, 64, 0, st>>>(w.counters, max_depth, n_paths, ctx->ws.stats);
+        k_stats<<<max_depth, 64, 0, st>>>(w.counters, max_depth, n_paths, shared ? np : n_paths, ctx->ws.stats);
     }
     PT_HIP_CHECK(hipGetLastError());
     ctx->last_w = width; ctx->last_h = height;
@@ -987,6 +1027,13 @@ int pt_trace_stats(PtContext* ctx, PtTraceStats* out)
     PT_HIP_CHECK(hipMemcpy(h, ctx->ws.stats, sizeof h, hipMemcpyDeviceToHost));
     for (int d = 0; d < PT_MAX_DEPTH; ++d) { out->rays_per_depth[d] = h[d]; out->rays += h[d]; }
     out->paths = h[PT_MAX_DEPTH];
+    return PT_OK;
+}
+
+int pt_ctx_set_share_primary(PtContext* ctx, int enabled)
+{
+    PT_REQUIRE(ctx, "null argument");
+    ctx->share_primary = enabled != 0;     // read when a frame is enqueued: frames in flight keep what they were enqueued with
     return PT_OK;
 }
 

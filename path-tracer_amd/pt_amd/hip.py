@@ -58,6 +58,7 @@ SIGNATURES = {
     "pt_trace_stats_reset": (_i, [_vp]),
     "pt_ctx_set_max_paths": (_i, [_vp, _u64]),
     "pt_ctx_set_profiling": (_i, [_vp, _i]),
+    "pt_ctx_set_share_primary": (_i, [_vp, _i]),
     "pt_trace_profile": (_i, [_vp, _vp]),
     "pt_accum_resolve": (_i, [_vp, _vp, _u32, _vp, _i]),
     "pt_accum_allreduce": (_i, [_vp, _vp, _u32, _u32]),
@@ -133,6 +134,10 @@ class Context:
 
     def set_max_paths(self, n):
         _check(self.lib.pt_ctx_set_max_paths(self.h, n))
+
+    def set_share_primary(self, enabled):
+        """Bounce 0 traced once per pixel and shared by the pixel's samples (identical images, fewer rays traversed)."""
+        _check(self.lib.pt_ctx_set_share_primary(self.h, int(enabled)))
 
     def close(self):
         if self.h:
