@@ -107,9 +107,12 @@ int pt_ctx_create(int device_id, void* hip_stream, PtContext** out)
         c->traversal_mode = strcmp(e, "plain") == 0 ? 0 : (strcmp(e, "sched") == 0 ? 1 : 2);
 #ifdef PT_EXPERIMENTAL
         if (strcmp(e, "pair") == 0) c->traversal_mode = 3;
+        if (strcmp(e, "pool") == 0) c->traversal_mode = 4;
+        if (strcmp(e, "autopool") == 0) c->traversal_mode = 5;
 #endif
     }
     if (const char* e = getenv("PT_HIP_SCHED_MIN_RAYS")) c->sched_min_rays = (uint32_t)strtoul(e, nullptr, 10);
+    if (const char* e = getenv("PT_HIP_POOL_MIN_RAYS")) c->pool_min_rays = (uint32_t)strtoul(e, nullptr, 10);
     if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
     else {
         hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);

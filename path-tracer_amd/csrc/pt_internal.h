@@ -148,7 +148,8 @@ struct PtContext {
     bool own_stream = false;
     int num_cus = 0;
     uint64_t max_paths = 1ull << 27;
-    int traversal_mode = 2;   // 0: one batch of 64 rays per wave at a time; 1: wave-scheduled with ray replacement; 2: chosen per level; (PT_HIP_TRAVERSAL=plain|sched|auto); 3, builds with PT_EXPERIMENTAL only: wave-scheduled with two rays per lane
+    int traversal_mode = 2;   // 0: one batch of 64 rays per wave at a time; 1: wave-scheduled with ray replacement; 2: chosen per level; (PT_HIP_TRAVERSAL=plain|sched|auto); builds with PT_EXPERIMENTAL only: 3 wave-scheduled with two rays per lane (pair), 4 / 5 rays pooled in LDS everywhere / above pool_min_rays (pool, autopool)
+    uint32_t pool_min_rays = 1200000;    // mode 4 (PT_HIP_TRAVERSAL=pool): levels with at least this many rays are traversed from LDS ray pools (PT_HIP_POOL_MIN_RAYS)
     uint32_t sched_min_rays = 1200000;   // mode 2: levels with at least this many rays are wave-scheduled (PT_HIP_SCHED_MIN_RAYS)
     // tables
     PtMaterial* materials = nullptr; uint32_t n_materials = 0;

@@ -27,6 +27,7 @@
 #include "pt_traverse_sched.h"
 #ifdef PT_EXPERIMENTAL
 #include "pt_traverse_pair.h"     // experimental/: two rays per lane, measured slower (make EXPERIMENTAL=1)
+#include "pt_traverse_pool.h"     // experimental/: rays pooled in LDS, lanes as workers, measured slower
 #endif
 #include <string.h>
 #include <algorithm>
@@ -208,6 +209,47 @@ k_intersect(PtTlasView tl, uint32_t* __restrict__ counters, uint32_t depth, uint
         }
     });
 }
+
+#ifdef PT_EXPERIMENTAL
+// traceRayEXT for every ray of one bounce with the rays of a wave pooled in LDS (pt_traverse_pool.h); levels below
+// sched_min_rays rays take the plain schedule, whose stack uses the start of the same LDS.
+template <bool BY_ID>
+__global__ void __launch_bounds__(kBlock, PT_POOL_WAVES)
+k_intersect_pool(PtTlasView tl, uint32_t* __restrict__ counters, uint32_t depth, uint32_t shard_cap,
+                 const float4* __restrict__ q0, const float4* __restrict__ q1, float tmin, float tmax,
+                 PtHit* __restrict__ hits, float* __restrict__ t_out, int* __restrict__ spill, uint32_t sched_min_rays)
+{
+    __shared__ int s_pool[PT_POOL_WORDS][PT_POOL_COLS];
+    __shared__ int s_class[kBlock / 64][32];
+    static_assert(sizeof(int) * PT_POOL_WORDS * PT_POOL_COLS >= sizeof(int) * PT_LDS_STACK * kBlock, "the plain schedule's stack lives in the pool's memory");
+    uint32_t total = counters[ctr_index(CTR_COUNT, depth, threadIdx.x & (kShards - 1))];   // lane s: shard s
+    for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off);
+    if (total >= sched_min_rays) {
+        PtSchedQueue Q;
+        Q.counters = counters; Q.shard_cap = shard_cap; Q.n_shards = kShards; Q.ctr_pad = kCtrPad;
+        Q.count_base = ctr_index(CTR_COUNT, depth, 0); Q.work_base = ctr_index(CTR_WORK_INTERSECT, depth, 0);
+        const uint32_t w = threadIdx.x >> 6;
+        const size_t first_slot = ((size_t)blockIdx.x * (kBlock / 64) + w) * PT_POOL_RAYS;
+        pt_traverse_pool<BY_ID>(tl, Q, (pt_lds_int*)&s_pool[0][w * PT_POOL_RAYS], (pt_lds_int*)&s_class[w][0], spill + first_slot * PT_SPILL_STACK,
+                                q0, q1, tmin, tmax, hits, t_out);
+        return;
+    }
+    PtStack stk;
+    stk.lds = (pt_lds_int*)&s_pool[0][0] + threadIdx.x;
+    stk.spill_base = spill;
+    for_each_batch<false>(counters, CTR_WORK_INTERSECT, depth, shard_cap, [&](uint32_t i, bool valid, uint32_t shard) {
+        if (valid) {
+            const float4 o = q0[i], d = q1[i];
+            PtHitRec h;
+            pt_closest_hit<false>(tl, stk, o.x, o.y, o.z, d.x, d.y, d.z, tmin, tmax, h);
+            PtHit out; out.instance = h.inst; out.primitive = h.prim; out.u = h.u; out.v = h.v;
+            const uint32_t dst = BY_ID ? __float_as_uint(d.w) : i;
+            hits[dst] = out;
+            if (BY_ID && t_out) t_out[dst] = h.t;
+        }
+    });
+}
+#endif
 
 #ifdef PT_EXPERIMENTAL
 // traceRayEXT for every ray of one bounce with two rays per lane (pt_traverse_pair.h): four waves per SIMD,
@@ -674,6 +716,16 @@ int persistent_blocks(PtContext* ctx, const void* kernel)
     return ctx->num_cus * per_cu;
 }
 
+#ifdef PT_EXPERIMENTAL
+// Grid of the pooled traversal: every slot of every wave owns a slice of the stack-overflow buffer, which was
+// sized for one slice per thread of the widest persistent grid.
+int pool_blocks(PtContext* ctx, const void* kernel)
+{
+    const int by_spill = (int)(((uint64_t)ctx->num_cus * 8 * kBlock) / PT_POOL_COLS);
+    return std::max(1, std::min(persistent_blocks(ctx, kernel), by_spill));
+}
+#endif
+
 // rays_only: the two ray streams alone (pt_intersect writes its results to the caller's arrays).
 int ensure_workspace(PtContext* ctx, PtLane& l, uint64_t paths, uint64_t pixels, bool rays_only = false)
 {
@@ -788,6 +840,8 @@ uint32_t sched_threshold(const PtContext* ctx, uint32_t depth)
 {
     if (ctx->traversal_mode == 0) return 0xFFFFFFFFu;        // plain everywhere
     if (ctx->traversal_mode == 1) return 0u;                 // scheduled everywhere
+    if (ctx->traversal_mode == 4) return 0u;                                              // pooled everywhere
+    if (ctx->traversal_mode == 5) return depth == 0 ? 0xFFFFFFFFu : ctx->pool_min_rays;   // pooled above the threshold, plain below
     if (ctx->traversal_mode == 3) return ctx->sched_min_rays; // (experimental two-rays-per-lane kernel: has its own launch; this is for entry points that do not use it)
     return depth == 0 ? 0xFFFFFFFFu : ctx->sched_min_rays;   // primary rays are coherent
 }
@@ -897,6 +951,13 @@ int pt_intersect(PtContext* ctx, const PtTlas* tlas, uint32_t n, const float* or
                                                               tmin, tmax, hits_dev, t_dev, w.spill);
         } else
 #endif
+#ifdef PT_EXPERIMENTAL
+        if (ctx->traversal_mode >= 4) {
+            const int blocks = pool_blocks(ctx, (const void*)k_intersect_pool<true>);
+            k_intersect_pool<true><<<blocks, kBlock, 0, st>>>(view_of(tlas), w.counters, 0, w.shard_cap, w.q[0][0], w.q[0][1],
+                                                              tmin, tmax, hits_dev, t_dev, w.spill, sched_threshold(ctx, 1));
+        } else
+#endif
         {
             const int blocks = persistent_blocks(ctx, (const void*)k_intersect<true>);
             k_intersect<true><<<blocks, kBlock, 0, st>>>(view_of(tlas), w.counters, 0, w.shard_cap, w.q[0][0], w.q[0][1],
@@ -930,6 +991,9 @@ int pt_trace(PtContext* ctx, const PtTlas* tlas, const float camera[32], uint32_
     memcpy(primary.camera.m, camera, sizeof primary.camera.m);
     primary.spp = spp; primary.W = width; primary.H = height; primary.frame = frame; primary.seed_mode = seed_mode;
     const int blocks_i = persistent_blocks(ctx, (const void*)k_intersect<false>);
+#ifdef PT_EXPERIMENTAL
+    const int blocks_pool = pool_blocks(ctx, (const void*)k_intersect_pool<false>);
+#endif
 #ifdef PT_EXPERIMENTAL
     const int blocks_pair = std::min(persistent_blocks(ctx, (const void*)k_intersect_pair<false>), ctx->num_cus * 4);   // two stack slices per thread
 #endif
@@ -986,6 +1050,12 @@ int pt_trace(PtContext* ctx, const PtTlas* tlas, const float camera[32], uint32_
                 if (ctx->traversal_mode == 3)
                     k_intersect_pair<false><<<blocks_pair, kBlock, 0, st>>>(tv, w.counters, d, w.shard_cap, w.q[a][0], w.q[a][1],
                                                                             0.001f, 10000.0f, w.hits, nullptr, w.spill);
+                else
+#endif
+#ifdef PT_EXPERIMENTAL
+                if (ctx->traversal_mode >= 4)
+                    k_intersect_pool<false><<<blocks_pool, kBlock, 0, st>>>(tv, w.counters, d, w.shard_cap, w.q[a][0], w.q[a][1],
+                                                                            0.001f, 10000.0f, w.hits, nullptr, w.spill, sched_threshold(ctx, d));
                 else
 #endif
                     k_intersect<false><<<blocks_i, kBlock, 0, st>>>(tv, w.counters, d, w.shard_cap, w.q[a][0], w.q[a][1],
