@@ -34,7 +34,7 @@ def source_hash():
     """Identifies the sources of the tracing kernels and of the traversal layout a PMC record was collected with."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "path-tracer_amd", "csrc")
-    for name in ("pt_trace.hip", "pt_device.h", "pt_traverse_sched.h", "pt_internal.h", "pt_wide.h", "pt_sah.h"):
+    for name in ("pt_trace.hip", "pt_device.h", "pt_traverse_sched.h", "pt_internal.h", "pt_wide.h", "pt_sah.h", "pt_build.hip"):
         with open(os.path.join(d, name), "rb") as f:
             h.update(name.encode() + b"\0" + f.read())
     return h.hexdigest()[:16]
@@ -58,19 +58,32 @@ def make_roofline(launches, total_ms, rays, n_simds, pmc, compulsory_bytes, surv
     The kernels are bound by vector-instruction issue, so that is the headline: achieved = wave64 vector
     instructions per launch (SQ_INSTS_VALU, PMC pass of the same workload and sources) / average launch
     duration; peak = 0.5 instructions per cycle per SIMD (what the 157.3 TFLOP/s fp32 figure implies)
-    x SIMDs x 2.4 GHz.  Beside it `hbm`: measured memory-side bytes per launch / duration against 8 TB/s,
-    and the bytes a launch cannot avoid (rays read, hit records and path state written).  `survey_model`
-    keeps the modelled bytes per ray of a binary BVH in full precision (32 B per box test, 36 B per
-    triangle test), which the quantised wide tree held in L2 does not move: it is not a bound."""
+    x SIMDs x 2.4 GHz.  `lane_utilisation` is the fraction of the 64 lanes that take part in an average vector
+    instruction (SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU)) and `useful_frac` = frac x lane_utilisation:
+    the share of the peak spent on lanes that hold a ray.  Beside it `hbm`: measured memory-side bytes per launch
+    / duration against 8 TB/s, and the bytes a launch cannot avoid (rays read, hit records and path state
+    written).  `survey_model` keeps the modelled bytes per ray of a binary BVH in full precision (32 B per box
+    test, 36 B per triangle test), which the quantised wide tree held in L2 does not move: it is not a bound."""
     avg_ms = total_ms / max(launches, 1)
     sec = avg_ms * 1e-3
     peak = VALU_PEAK_PER_SIMD * n_simds * CLOCK_GHZ      # G wave-instructions per second
     insts = float(pmc["valu_insts_per_launch"]) if pmc and pmc.get("valu_insts_per_launch") else None
     traffic = float(pmc["bytes_per_launch"]) if pmc and pmc.get("bytes_per_launch") else None
+    lanes = float(pmc["lane_utilisation"]) if pmc and pmc.get("lane_utilisation") else None
     achieved = insts / sec / 1e9 if insts and sec > 0 else None
+    frac = achieved / peak if achieved is not None else None
+    # the same per kernel, where the PMC record holds the kernels apart
+    per_kernel = {k: dict(v) for k, v in per_kernel.items()}
+    for k, v in per_kernel.items():
+        rec = (pmc or {}).get("kernels", {}).get(k)
+        if rec and v.get("avg_launch_ms", 0) > 0:
+            a = rec["valu_insts_per_launch"] / (v["avg_launch_ms"] * 1e-3) / 1e9
+            v.update({"valu_insts_per_launch": rec["valu_insts_per_launch"], "frac": a / peak, "lane_utilisation": rec["lane_utilisation"],
+                      "useful_frac": a / peak * rec["lane_utilisation"],
+                      "hbm_frac": (rec["fetch_bytes_per_launch"] + rec["write_bytes_per_launch"]) / (v["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS})
     out = {
         "bound": "valu", "kernel": "k_intersect + k_primary", "achieved": achieved, "peak": peak, "unit": "G wave64 vector instructions/s",
-        "frac": achieved / peak if achieved is not None else None, "traffic": traffic,
+        "frac": frac, "traffic": traffic, "lane_utilisation": lanes, "useful_frac": frac * lanes if frac is not None and lanes is not None else None,
         "launches": launches, "avg_launch_ms": avg_ms, "rays_per_launch": rays / max(launches, 1), "frames_in_flight": frames_in_flight,
         "valu_insts_per_launch": insts, "valu_insts_per_ray": insts * launches / rays if insts and rays else None,
         "insts_per_cycle_per_simd": achieved / (n_simds * CLOCK_GHZ) if achieved is not None else None,
@@ -90,6 +103,25 @@ def make_roofline(launches, total_ms, rays, n_simds, pmc, compulsory_bytes, surv
                                "modelled_gbs": rays * survey_bytes_per_ray / (total_ms * 1e-3) / 1e9 if total_ms > 0 else 0.0,
                                "note": "box and triangle tests of the CPU port's binary BVH x 32 B / 36 B + 48 B per ray; a model, not traffic and not a bound"}
     return out
+
+
+def roofline_from_profile(p, rays_per_depth, n_frames_stats, n_simds, wkey, survey, frames_in_flight):
+    """make_roofline from a PtTraceProfile (event-timed traversal launches) and the rays per bounce of the same frames."""
+    i_ms = float(p["intersect_ms"]) + float(p["primary_ms"])
+    i_rays = float(p["intersect_rays"]) + float(p["primary_rays"])
+    i_n = int(p["intersect_launches"]) + int(p["primary_launches"])
+    per_kernel = {
+        "k_primary": {"launches": int(p["primary_launches"]), "avg_launch_ms": float(p["primary_ms"]) / max(int(p["primary_launches"]), 1),
+                      "rays_per_launch": float(p["primary_rays"]) / max(int(p["primary_launches"]), 1)},
+        "k_intersect": {"launches": int(p["intersect_launches"]), "avg_launch_ms": float(p["intersect_ms"]) / max(int(p["intersect_launches"]), 1),
+                        "rays_per_launch": float(p["intersect_rays"]) / max(int(p["intersect_launches"]), 1)}}
+    # bytes a traversal launch cannot avoid: k_intersect reads a 32-byte ray and writes a 16-byte hit record per
+    # ray; k_primary writes 64 bytes of path state per surviving path and a 16-byte result per path that ends
+    frames_roof = max(int(p["primary_launches"]), 1)
+    per_frame = [x / max(n_frames_stats, 1) for x in rays_per_depth]
+    survivors = per_frame[1] if len(per_frame) > 1 else 0.0
+    compulsory = frames_roof * (48.0 * sum(per_frame[1:]) + 64.0 * survivors + 16.0 * (per_frame[0] - survivors))
+    return make_roofline(i_n, i_ms, i_rays, n_simds, pmc_record(wkey), compulsory, survey, frames_in_flight, per_kernel)
 
 
 def build_scene(name):
@@ -197,6 +229,7 @@ def main():
     ap.add_argument("--max-paths", type=int, default=0,
                     help="paths per pixel chunk (library default 2^27); 0: the whole step in one chunk (at most 2^31 - 1 paths)")
     ap.add_argument("--max-depth", type=int, default=10)
+    ap.add_argument("--max-leaf", type=int, default=0, help="largest BLAS leaf, in triangles (0: the library's default)")
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="steps the library keeps in flight on separate streams; 0 (default): one or two, whichever four timed "
                          "warm-up steps show to be faster on this machine (two must win by 1 %% to pay for the second set of queues)")
@@ -274,7 +307,7 @@ def main():
     stream = side.cuda_stream
     assert stream != 0
     t0 = time.perf_counter()
-    r = hip.Renderer(scene, W, H, device=local_rank, stream=stream, camera=cam)
+    r = hip.Renderer(scene, W, H, device=local_rank, stream=stream, camera=cam, max_leaf=args.max_leaf)
     torch.cuda.synchronize()
     setup_s = time.perf_counter() - t0
     r.ctx.set_share_primary(args.share_primary)
@@ -436,25 +469,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(scene, cam, W, H, args.cpu_spp, args.max_depth)
             out["cpu_baseline"] = {k: cpu[k] for k in ("value", "unit", "cores", "kind", "sample", "host_logical_cpus", "paths_per_s")}
-        p = prof_roof
-        i_ms = float(p["intersect_ms"]) + float(p["primary_ms"])
-        i_rays = float(p["intersect_rays"]) + float(p["primary_rays"])
-        i_n = int(p["intersect_launches"]) + int(p["primary_launches"])
-        per_kernel = {
-            "k_primary": {"launches": int(p["primary_launches"]), "avg_launch_ms": float(p["primary_ms"]) / max(int(p["primary_launches"]), 1),
-                          "rays_per_launch": float(p["primary_rays"]) / max(int(p["primary_launches"]), 1)},
-            "k_intersect": {"launches": int(p["intersect_launches"]), "avg_launch_ms": float(p["intersect_ms"]) / max(int(p["intersect_launches"]), 1),
-                            "rays_per_launch": float(p["intersect_rays"]) / max(int(p["intersect_launches"]), 1)}}
-        # bytes a traversal launch cannot avoid: k_intersect reads a 32-byte ray and writes a 16-byte hit record per
-        # ray; k_primary writes 64 bytes of path state per surviving path and a 16-byte result per path that ends
-        frames_roof = max(int(p["primary_launches"]), 1)
-        per_frame = [x / max(len(my_timed), 1) for x in rays_per_depth]
-        survivors = per_frame[1] if len(per_frame) > 1 else 0.0
-        compulsory = frames_roof * (48.0 * sum(per_frame[1:]) + 64.0 * survivors + 16.0 * (per_frame[0] - survivors))
         survey = (32.0 * cpu["box_tests_per_ray"] + 36.0 * cpu["tri_tests_per_ray"] + 48.0) if cpu else None
         wkey = f"{args.scene} {W}x{H} {args.spp}spp depth{args.max_depth}"
         n_simds = 4 * torch.cuda.get_device_properties(local_rank).multi_processor_count
-        out["roofline"] = make_roofline(i_n, i_ms, i_rays, n_simds, pmc_record(wkey), compulsory, survey, roof_fif, per_kernel)
+        out["roofline"] = roofline_from_profile(prof_roof, rays_per_depth, len(my_timed), n_simds, wkey, survey, roof_fif)
         out["roofline"]["durations_from"] = ("the timed region" if prof_roof is prof else "three steps after the timed region") + \
                                             f", {roof_fif} frame(s) in flight" + ("" if roof_fif == 1 else ": launches overlap, durations are stretched")
         if world == 1 and not args.no_secondary and not args.share_primary:
@@ -493,6 +511,17 @@ def main():
             s2 = c.stats()
             out["cornell"] = {"rays_per_s": int(s2["rays"]) / dt, "paths_per_s": int(s2["paths"]) / dt, "ms_per_step": 1e3 * dt / 3, "steps": 3,
                               "workload": f"cornell {W}x{H}, {args.spp} spp per step, max depth {args.max_depth}, after the timed region"}
+            # its own roofline: two more steps, one at a time, every traversal launch between HIP events
+            c.ctx.set_frames_in_flight(1)
+            c.reset_stats()
+            c.set_profiling(True)
+            c.profile()
+            run_frames(c, acc2.data_ptr(), range(10, 12), args.spp, args.max_depth)
+            pc = c.profile()
+            c.set_profiling(False)
+            s2 = c.stats()
+            out["cornell"]["roofline"] = roofline_from_profile(pc, [int(x) for x in s2["rays_per_depth"][:args.max_depth]], 2, n_simds,
+                                                               f"cornell {W}x{H} {args.spp}spp depth{args.max_depth}", None, 1)
             c.close()
         print(json.dumps(out))
     if world > 1:

@@ -178,6 +178,12 @@ int pt_tlas_destroy(PtTlas* tlas);   /* top_level_...cpp:16 */
 int pt_tlas_info(const PtTlas* tlas, PtAsInfo* out);
 int pt_tlas_download(const PtTlas* tlas, PtBvhNode* nodes, uint32_t* leaf_instances,
                      float* instance_boxes /* n x 6 */, float* instance_w2o /* n x 12 */);
+/* The binary tree the TLAS's wide nodes are derived from and the instance at each of its leaf positions: the
+ * cheaper, in the surface-area model, of the Morton tree of pt_tlas_download and a full-sweep SAH tree over the
+ * instance boxes (the driver is asked for ePreferFastTrace, top_level_acceleration_structure.cpp:75);
+ * PT_HIP_TLAS_TREE=lbvh|sweep forces one.  The closest hit does not depend on the tree.  nodes may be NULL to
+ * query the count. */
+int pt_tlas_traversal_download(const PtTlas* tlas, PtBvhNode* nodes, uint32_t capacity, uint32_t* leaf_instances, uint32_t* count_out);
 int pt_tlas_wide_download(const PtTlas* tlas, void* nodes64, uint32_t capacity, uint32_t* count_out, uint32_t* depth_out);
 
 /* Replaces BindlessResources::UpdateDescriptorSet (source/resources/bindless_resources.cpp:70-76,

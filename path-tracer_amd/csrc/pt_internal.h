@@ -79,7 +79,10 @@ struct PtTlas {
     float4* pool_tris;              // device: triangle records of every distinct BLAS, 3 float4 each
     uint32_t pool_node_count;
     uint32_t wide_count, wide_depth;  // the TLAS's own wide nodes: the first wide_count of the pool
-    uint32_t* leaf_inst;            // device, instance index per sorted slot
+    uint32_t* leaf_inst;            // device, instance index per sorted slot (Morton tree)
+    PtBvhNode* trav_nodes;          // device: full-sweep SAH tree over the instance boxes the wide nodes are derived from (null: the Morton tree is)
+    uint32_t trav_node_count;
+    std::vector<uint32_t> trav_order;   // instance at each leaf position of that tree
     PtDevInstance* inst;            // device, n, in leaf-slot order
     PtDevShadeInstance* shade_inst; // device, n; rebuilt when the context's tables change
     uint64_t shade_version;         // ctx->tables_version the records were built from

@@ -189,3 +189,79 @@ static inline void pt_sah_build_host(const float* boxes, uint32_t n, uint32_t ma
         level.swap(next);
     }
 }
+
+// Full-sweep SAH tree over a few boxes (the instances of a TLAS): every object partition along the three axes by
+// centroid order is priced with area(L) * n(L) + area(R) * n(R) and the cheapest taken (first minimum in axis-major,
+// position-ascending order; centroids are ordered by (value, index)); one box per leaf.  The Morton tree that is
+// compared with the CPU port orders a handful of large, overlapping instance boxes (the walls of a room, the parts of
+// one object) more or less arbitrarily; this tree is what the traversal layout of a TLAS is derived from, and like
+// every tree over the same boxes it changes which boxes a ray tests, never what it hits.
+// boxes: n x 6; nodes_out[0] is the root (n > 1); order_out[p] = box at leaf position p.
+static inline void pt_sweep_sah_build_host(const float* boxes, uint32_t n, std::vector<PtBvhNode>& nodes_out, std::vector<uint32_t>& order_out)
+{
+    nodes_out.clear(); order_out.resize(n);
+    for (uint32_t i = 0; i < n; ++i) order_out[i] = i;
+    if (n < 2) return;
+    const float inf = __builtin_inff();
+    struct Range { uint32_t a, b; int32_t parent; uint32_t side; };
+    std::vector<Range> todo { Range { 0, n, -1, 0 } };
+    std::vector<uint32_t> sorted, best_sorted;
+    std::vector<float> suffix;
+    for (size_t head = 0; head < todo.size(); ++head) {
+        const Range r = todo[head];
+        const uint32_t m = r.b - r.a;
+        int32_t ref;
+        if (m == 1) ref = pt_sah_leaf_ref(r.a, 1);
+        else {
+            float best = inf; uint32_t best_k = m / 2; bool have = false;
+            for (int ax = 0; ax < 3; ++ax) {
+                sorted.assign(order_out.begin() + r.a, order_out.begin() + r.b);
+                std::stable_sort(sorted.begin(), sorted.end(), [&](uint32_t x, uint32_t y) {
+                    const float cx = pt_sah_centroid(boxes + 6 * (size_t)x, ax), cy = pt_sah_centroid(boxes + 6 * (size_t)y, ax);
+                    return cx < cy || (cx == cy && x < y);
+                });
+                suffix.assign(m + 1, 0.0f);
+                float lo[3] = { inf, inf, inf }, hi[3] = { -inf, -inf, -inf };
+                for (uint32_t k = m; k-- > 1;) {
+                    const float* x = boxes + 6 * (size_t)sorted[k];
+                    for (int c = 0; c < 3; ++c) { lo[c] = fminf(lo[c], x[c]); hi[c] = fmaxf(hi[c], x[3 + c]); }
+                    suffix[k] = pt_sah_area(lo, hi);
+                }
+                for (int c = 0; c < 3; ++c) { lo[c] = inf; hi[c] = -inf; }
+                for (uint32_t k = 1; k < m; ++k) {          // the first k boxes go left
+                    const float* x = boxes + 6 * (size_t)sorted[k - 1];
+                    for (int c = 0; c < 3; ++c) { lo[c] = fminf(lo[c], x[c]); hi[c] = fmaxf(hi[c], x[3 + c]); }
+                    const float cost = pt_sah_area(lo, hi) * (float)k + suffix[k] * (float)(m - k);
+                    if (cost < best) { best = cost; best_k = k; best_sorted = sorted; have = true; }
+                }
+            }
+            if (have) std::copy(best_sorted.begin(), best_sorted.end(), order_out.begin() + r.a);
+            const uint32_t mid = r.a + best_k;
+            PtBvhNode nd; memset(&nd, 0, sizeof nd);
+            for (int c = 0; c < 3; ++c) { nd.lo0[c] = inf; nd.hi0[c] = -inf; nd.lo1[c] = inf; nd.hi1[c] = -inf; }
+            for (uint32_t i = r.a; i < r.b; ++i) {
+                const float* x = boxes + 6 * (size_t)order_out[i];
+                float* lo = i < mid ? nd.lo0 : nd.lo1; float* hi = i < mid ? nd.hi0 : nd.hi1;
+                for (int c = 0; c < 3; ++c) { lo[c] = fminf(lo[c], x[c]); hi[c] = fmaxf(hi[c], x[3 + c]); }
+            }
+            ref = (int32_t)nodes_out.size();
+            nodes_out.push_back(nd);
+            todo.push_back(Range { r.a, mid, ref, 0 });
+            todo.push_back(Range { mid, r.b, ref, 1 });
+        }
+        if (r.parent >= 0) { if (r.side) nodes_out[r.parent].c1 = ref; else nodes_out[r.parent].c0 = ref; }
+    }
+}
+
+// Expected box tests of a ray that enters the root, in the surface-area model: the areas of all child boxes relative to
+// the root's.  What decides between two trees over the same boxes.
+static inline double pt_tree_cost_host(const PtBvhNode* nodes, size_t n)
+{
+    if (n == 0) return 0.0;
+    float lo[3], hi[3];
+    for (int c = 0; c < 3; ++c) { lo[c] = fminf(nodes[0].lo0[c], nodes[0].lo1[c]); hi[c] = fmaxf(nodes[0].hi0[c], nodes[0].hi1[c]); }
+    const double root = pt_sah_area(lo, hi);
+    double sum = 0.0;
+    for (size_t i = 0; i < n; ++i) sum += (double)pt_sah_area(nodes[i].lo0, nodes[i].hi0) + (double)pt_sah_area(nodes[i].lo1, nodes[i].hi1);
+    return root > 0.0 ? sum / root : 0.0;
+}

@@ -34,6 +34,18 @@ uint32_t pt_sah_build_host_c(const float* boxes, uint32_t n, uint32_t max_leaf, 
     return (uint32_t)nodes.size();
 }
 
+// Full-sweep SAH tree over n boxes (the TLAS traversal tree): nodes_out capacity n, order_out n; returns the node count.
+uint32_t pt_sweep_sah_build_host_c(const float* boxes, uint32_t n, PtBvhNode* nodes_out, uint32_t* order_out)
+{
+    std::vector<PtBvhNode> nodes; std::vector<uint32_t> ids;
+    pt_sweep_sah_build_host(boxes, n, nodes, ids);
+    memcpy(nodes_out, nodes.data(), sizeof(PtBvhNode) * nodes.size());
+    memcpy(order_out, ids.data(), sizeof(uint32_t) * n);
+    return (uint32_t)nodes.size();
+}
+
+double pt_tree_cost_host_c(const PtBvhNode* nodes, uint32_t n) { return pt_tree_cost_host(nodes, n); }
+
 // Writes the leaf codes (first << 3 | count - 1) of every leaf whose chain of dequantised boxes the
 // ray interval [tlo, thi] overlaps, in traversal order without any pruning by found hits.
 uint32_t pt_wide_candidates_host(const void* wide, uint32_t root, const float o[3], const float d[3],

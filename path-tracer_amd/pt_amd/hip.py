@@ -45,6 +45,7 @@ SIGNATURES = {
     "pt_blas_wide_download": (_i, [_vp, _vp, _u32, _vp, _vp]),
     "pt_blas_traversal_download": (_i, [_vp, _vp, _u32, _vp, _vp]),
     "pt_tlas_wide_download": (_i, [_vp, _vp, _u32, _vp, _vp]),
+    "pt_tlas_traversal_download": (_i, [_vp, _vp, _u32, _vp, _vp]),
     "pt_tlas_build": (_i, [_vp, _vp, _u32, C.POINTER(_vp)]),
     "pt_tlas_destroy": (_i, [_vp]),
     "pt_tlas_info": (_i, [_vp, _vp]),
@@ -245,6 +246,15 @@ class TopLevelAccelerationStructure:
         w2o = np.zeros((self.n, 12), dtype=np.float32)
         _check(self.ctx.lib.pt_tlas_download(self.h, _p(nodes), _p(leaf), _p(boxes), _p(w2o)))
         return nodes, leaf, boxes, w2o
+
+    def download_traversal_tree(self):
+        """(binary nodes, instance per leaf position) of the tree the wide nodes are derived from."""
+        cnt = C.c_uint32(0)
+        _check(self.ctx.lib.pt_tlas_traversal_download(self.h, None, 0, None, C.byref(cnt)))
+        nodes = np.zeros(cnt.value, dtype=abi.BVH_NODE)
+        inst = np.zeros(self.n, dtype=np.uint32)
+        _check(self.ctx.lib.pt_tlas_traversal_download(self.h, _p(nodes), cnt.value, _p(inst), None))
+        return nodes, inst
 
     def download_wide(self):
         """(wide nodes, depth) of the traversal layout."""

@@ -264,6 +264,99 @@ def test_sah_tree_is_a_partition_with_exact_boxes(name, request, wide_lib):
             assert sah_cost(nodes) < 0.92 * sah_cost(b.nodes())      # what the second tree is for
 
 
+def sweep_host(lib, boxes):
+    n = len(boxes)
+    nodes = np.zeros(n, dtype=abi.BVH_NODE)
+    order = np.zeros(n, dtype=np.uint32)
+    lib.pt_sweep_sah_build_host_c.restype = C.c_uint32
+    lib.pt_sweep_sah_build_host_c.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    cnt = lib.pt_sweep_sah_build_host_c(boxes.ctypes.data, n, nodes.ctypes.data, order.ctypes.data)
+    return nodes[:cnt].copy(), order
+
+
+def _instance_boxes(orc):
+    return np.ascontiguousarray(np.stack([np.concatenate(orc.tlas.instance_box(i)) for i in range(orc.tlas.n)]).astype(np.float32))
+
+
+@pytest.mark.parametrize("name", ["cornell", "soup", "helmet", "stacked"])
+def test_tlas_sweep_tree_is_a_partition_with_exact_boxes(name, request, wide_lib):
+    """The full-sweep SAH tree a TLAS may be traversed through: one instance per leaf, every instance in exactly one
+    leaf, child boxes the exact unions of the instance boxes below them, wide nodes conservative; and it never costs
+    more than splitting every range in the middle of its original order."""
+    scene = request.getfixturevalue(name)
+    orc = O.OracleScene(scene)
+    boxes = _instance_boxes(orc)
+    if len(boxes) < 2:
+        pytest.skip("one instance: no tree")
+    nodes, order = sweep_host(wide_lib, boxes)
+    assert len(nodes) == len(boxes) - 1
+    check_binary_tree(nodes, order, boxes, 1)
+    wide, depth = collapse(wide_lib, nodes)
+    check_wide(wide, depth, boxes[order][:, :3], boxes[order][:, 3:], len(boxes))
+    # the same boxes in a random order give a tree of the same cost class (the sweep looks at every partition along the axes)
+    rng = np.random.default_rng(5)
+    perm = rng.permutation(len(boxes))
+    nodes2, order2 = sweep_host(wide_lib, np.ascontiguousarray(boxes[perm]))
+    check_binary_tree(nodes2, order2, boxes[perm], 1)
+    wide_lib.pt_tree_cost_host_c.restype = C.c_double
+    wide_lib.pt_tree_cost_host_c.argtypes = [C.c_void_p, C.c_uint32]
+    c1 = wide_lib.pt_tree_cost_host_c(nodes.ctypes.data, len(nodes)); c2 = wide_lib.pt_tree_cost_host_c(nodes2.ctypes.data, len(nodes2))
+    assert abs(c1 - c2) <= 0.15 * max(c1, c2)
+    assert abs(c1 - (sah_cost(nodes) - 1.0 + _leaf_child_area(nodes))) < 1e-3 * c1
+
+
+def _leaf_child_area(nodes):
+    """Areas of the leaf children relative to the root (sah_cost counts the inner children only)."""
+    def area(lo, hi):
+        d = np.maximum(hi - lo, 0).astype(np.float64)
+        return d[..., 0] * d[..., 1] + d[..., 1] * d[..., 2] + d[..., 2] * d[..., 0]
+    root = area(np.minimum(nodes["lo0"][0], nodes["lo1"][0]), np.maximum(nodes["hi0"][0], nodes["hi1"][0]))
+    c = 0.0
+    for ck, lo, hi in (("c0", "lo0", "hi0"), ("c1", "lo1", "hi1")):
+        leaf = nodes[ck] < 0
+        c += area(nodes[lo][leaf], nodes[hi][leaf]).sum() / root
+    return c
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["cornell", "helmet", "soup", "stacked"])
+def test_gpu_tlas_traversal_tree_is_the_cheaper_one(name, request, wide_lib, monkeypatch):
+    """pt_tlas_build traverses the cheaper of the Morton tree and the host's full-sweep SAH tree; forced either way,
+    frames are the same bits."""
+    from pt_amd import hip
+    scene = request.getfixturevalue(name)
+    orc = O.OracleScene(scene)
+    boxes = _instance_boxes(orc)
+    wide_lib.pt_tree_cost_host_c.restype = C.c_double
+    wide_lib.pt_tree_cost_host_c.argtypes = [C.c_void_p, C.c_uint32]
+    cost = lambda nd: wide_lib.pt_tree_cost_host_c(np.ascontiguousarray(nd).ctypes.data, len(nd))
+    frames = {}
+    for forced in (None, "lbvh", "sweep"):
+        if forced:
+            monkeypatch.setenv("PT_HIP_TLAS_TREE", forced)
+        else:
+            monkeypatch.delenv("PT_HIP_TLAS_TREE", raising=False)
+        r = hip.Renderer(scene, 48, 32)
+        try:
+            morton = r.tlas.download()[0]
+            nodes, order = r.tlas.download_traversal_tree()
+            want_nodes, want_order = sweep_host(wide_lib, boxes)
+            if forced == "lbvh":
+                assert nodes.tobytes() == morton.tobytes()
+            elif forced == "sweep":
+                assert nodes.tobytes() == want_nodes.tobytes() and np.array_equal(order, want_order)
+            else:
+                cheaper_is_sweep = cost(want_nodes) < cost(morton)
+                assert nodes.tobytes() == (want_nodes if cheaper_is_sweep else morton).tobytes()
+            check_binary_tree(nodes, order, boxes, 1)
+            r.render(spp=3, frame=1)
+            frames[forced] = r.last_result().copy()
+        finally:
+            r.close()
+    assert np.array_equal(frames[None].view(np.uint32), frames["lbvh"].view(np.uint32))
+    assert np.array_equal(frames[None].view(np.uint32), frames["sweep"].view(np.uint32))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["cornell", "soup", "dragon", "stacked", "helmet"])
 def test_gpu_sah_builder_matches_host_twin(name, request, wide_lib):
@@ -299,7 +392,7 @@ def test_gpu_builder_matches_host_collapse(name, request, wide_lib):
             got, depth = b.download_wide()
             want, want_depth = collapse(wide_lib, nodes)
             assert depth == want_depth and got.tobytes() == want.tobytes()
-        nodes = r.tlas.download()[0]
+        nodes = r.tlas.download_traversal_tree()[0]
         got, depth = r.tlas.download_wide()
         want, want_depth = collapse(wide_lib, nodes)
         assert depth == want_depth and got.tobytes() == want.tobytes()

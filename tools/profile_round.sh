@@ -32,15 +32,23 @@ if [ -z "${SKIP_CONFIGS:-}" ]; then
 fi
 # lane utilisation of the scheduled traversals (needs variants/stats.so: tools/build_variant.sh stats -DPT_SCHED_STATS)
 if [ -f variants/stats.so ]; then
-  for mode in auto pair; do
-    SPP=64 PT_HIP_LIB=variants/stats.so PT_HIP_TRAVERSAL=$mode timeout -k 10 200 python3 tools/sched_stats.py > $out/sched_stats_$mode.txt 2>&1
+  for c in dragon cornell helmet; do
+    SPP=32 PT_HIP_LIB=variants/stats.so PT_HIP_SCHED_MIN_RAYS=0 timeout -k 10 200 python3 tools/sched_stats.py $c > $out/sched_stats_$c.txt 2>&1
   done
-  bash tools/ab_env.sh "auto:PT_X=0" "pair:PT_HIP_TRAVERSAL=pair" "sched:PT_HIP_TRAVERSAL=sched" "plain:PT_HIP_TRAVERSAL=plain" > $out/schedules_ab.txt 2>&1
+  SPP=8 PT_HIP_LIB=variants/stats.so PT_HIP_SCHED_MIN_RAYS=0 timeout -k 10 300 python3 tools/sched_stats.py composite 3840 2160 > $out/sched_stats_composite.txt 2>&1
+  bash tools/ab_env.sh "auto:PT_X=0" "sched:PT_HIP_TRAVERSAL=sched" "plain:PT_HIP_TRAVERSAL=plain" > $out/schedules_ab.txt 2>&1
 fi
 [ -n "${SKIP_PMC:-}" ] && { echo done; exit 0; }
 bash tools/pmc_passes.sh $out/pmc --steps 3 --warmup 3 --frames-in-flight 1 > $out/pmc.log 2>&1 || { tail -5 $out/pmc.log; exit 1; }
 bash tools/pmc_passes2.sh $out/pmc2 --steps 3 --warmup 3 --frames-in-flight 1 >> $out/pmc.log 2>&1 || { tail -5 $out/pmc.log; exit 1; }
 python3 tools/pmc_summary.py $out/pmc > $out/pmc_summary.txt
 python3 tools/pmc_summary.py $out/pmc2 >> $out/pmc_summary.txt
-python3 tools/pmc_traffic.py $out/pmc --no-cpu-baseline --steps 3 --warmup 3 --frames-in-flight 1 > $out/traffic_entry.json
+python3 tools/pmc_traffic.py $out/pmc --key "dragon 1920x1080 256spp depth10" -- --no-cpu-baseline --steps 3 --warmup 3 --frames-in-flight 1 > $out/traffic_dragon.json
+# the other scenes of the metric and of BASELINE's configurations: the four passes the roofline needs
+for c in cornell helmet composite; do
+  case $c in composite) extra="--width 3840 --height 2160 --spp 64"; key="composite 3840x2160 64spp depth10";; *) extra=""; key="$c 1920x1080 256spp depth10";; esac
+  PMC_MIN=1 PMC_TIMEOUT=200 bash tools/pmc_passes.sh $out/pmc_$c --scene $c $extra --steps 2 --warmup 2 --frames-in-flight 1 >> $out/pmc.log 2>&1 || { tail -5 $out/pmc.log; exit 1; }
+  python3 tools/pmc_traffic.py $out/pmc_$c --key "$key" -- --scene $c $extra --no-cpu-baseline --steps 2 --warmup 2 --frames-in-flight 1 > $out/traffic_$c.json
+  python3 tools/pmc_summary.py $out/pmc_$c > $out/pmc_summary_$c.txt
+done
 echo done
