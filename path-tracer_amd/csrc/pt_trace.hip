@@ -365,15 +365,18 @@ __device__ __forceinline__ void shade_batch(const PtShadeArgs& S, const PtDevSha
     if (cnt && lane == 0) slot0 = atomicAdd(&S.counters[ctr_index(CTR_COUNT, S.depth + 1, shard)], cnt);
     float4 no, nd, nw, nh;
     if (valid) {
-        uint32_t seed_in, path;
-        if (FIRST) pt_primary_seed(S.primary, path_of_slot(i, shard, S.shard_cap), seed_in, path);
         // cw, hv: path weight and collected radiance; bounces after the first carry the seed and the
-        // result slot in their spare words (the incoming ray is not needed here)
-        if (!FIRST) { seed_in = __float_as_uint(cw.w); path = __float_as_uint(hv.w); }
+        // result slot in their spare words (the incoming ray is not needed here).  At bounce 0 the result slot
+        // is the path index and the seed (16 rounds of TEA) is only worked out for a path that hits something:
+        // a miss never draws a random number (miss.rmiss:8-21)
+        uint32_t seed_in = 0, path;
+        if (FIRST) path = path_of_slot(i, shard, S.shard_cap);
+        else { seed_in = __float_as_uint(cw.w); path = __float_as_uint(hv.w); }
         if (h.instance == 0xFFFFFFFFu) {
             shade_miss(S.depth, cw, hv);
             path_result[path] = hv;
         } else {
+            if (FIRST) { uint32_t slot_unused; pt_primary_seed(S.primary, path, seed_in, slot_unused); }
             // closest_hit.rchit:57-60 (table chain pre-resolved per instance)
             const PtDevShadeInstance& I = shade_inst[h.instance];
             const float4 ptrs = I.ptrs;

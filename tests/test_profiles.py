@@ -44,7 +44,14 @@ def test_bench_line_contract(path):
         assert key in r, key
     assert r["bound"] == "valu" and r["peak"] == 0.5 * r["simds"] * r["clock_ghz"]
     assert r["frames_in_flight"] == 1, "per-kernel durations must come from launches that had the GPU to themselves"
-    if r["frac"] is not None:        # a PMC record exists for this workload
+    assert r["frac"] is not None, "every configuration has a PMC record of its own (tools/profile_round.sh)"
+    assert r["pmc_source"]["stale"] is False
+    assert 0.0 < r["lane_utilisation"] <= 1.0 and abs(r["useful_frac"] - r["frac"] * r["lane_utilisation"]) < 1e-12
+    for k in ("k_primary", "k_intersect"):
+        pk = r["per_kernel"][k]
+        assert 0.0 < pk["frac"] <= 1.0 and 0.0 < pk["lane_utilisation"] <= 1.0 and 0.0 < pk["hbm_frac"] <= 1.0
+        assert abs(pk["useful_frac"] - pk["frac"] * pk["lane_utilisation"]) < 1e-12
+    if r["frac"] is not None:
         assert 0.0 < r["frac"] <= 1.0 and 0.0 < r["hbm"]["frac"] <= 1.0
         assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
         assert abs(r["achieved"] - r["valu_insts_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-9
@@ -99,14 +106,52 @@ def test_roofline_can_be_recomputed_from_the_committed_profiles():
     assert abs(hbm - r["hbm"]["frac"]) < 0.01 and hbm <= 1.0
 
 
+def test_cornell_roofline_can_be_recomputed_from_the_committed_profiles():
+    """The metric's second scene: the `cornell` object of the default line carries its own roofline, and it follows
+    from the Cornell PMC record and the rocprofv3 kernel statistics of a separate Cornell run."""
+    j = _default_line()
+    r = j["cornell"]["roofline"]
+    rec = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["cornell 1920x1080 256spp depth10"]
+    assert rec["source_hash"] == bench.source_hash() and r["pmc_source"]["stale"] is False
+    assert abs(rec["valu_insts_per_launch"] - r["valu_insts_per_launch"]) < 1.0 and abs(rec["lane_utilisation"] - r["lane_utilisation"]) < 1e-12
+    ns, calls = 0.0, 0
+    for row in csv.DictReader(open(os.path.join(ROOT, "profiles", PREFIX + "cfg_cornell_kernel_stats.csv"))):
+        if "k_intersect" in row["Name"] or "k_primary" in row["Name"]:
+            ns += float(row["TotalDurationNs"]); calls += int(row["Calls"])
+    avg_ms = ns / calls / 1e6
+    assert abs(avg_ms - r["avg_launch_ms"]) / avg_ms < 0.05       # two separate runs
+    frac = rec["valu_insts_per_launch"] / (avg_ms * 1e-3) / 1e9 / r["peak"]
+    assert abs(frac - r["frac"]) < 0.03 and frac <= 1.0
+    assert abs(r["useful_frac"] - r["frac"] * r["lane_utilisation"]) < 1e-12
+    # and the Cornell configuration line of its own agrees with the object of the default line
+    cfg2 = _line(os.path.join(ROOT, "profiles", PREFIX + "cfg2_cornell_1080p.json"))["roofline"]
+    assert abs(cfg2["frac"] - r["frac"]) < 0.03
+
+
+def test_lane_utilisation_follows_from_the_counters():
+    """lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU), recomputed from the committed PMC summary."""
+    vals = {}
+    kernel = None
+    for line in open(os.path.join(ROOT, "profiles", PREFIX + "pmc.txt")):
+        if line.startswith("== "):
+            kernel = line.split()[1]
+        elif kernel and "sum=" in line:
+            vals.setdefault(kernel, {})[line.split()[0]] = float(line.split("sum=")[1].split()[0])
+    rec = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["dragon 1920x1080 256spp depth10"]
+    for k in ("k_primary", "k_intersect"):
+        lanes = vals[k]["SQ_THREAD_CYCLES_VALU"] / (64.0 * vals[k]["SQ_ACTIVE_INST_VALU"])
+        assert abs(lanes - rec["kernels"][k]["lane_utilisation"]) < 2e-3          # the summary prints four digits
+
+
 def test_make_roofline_fractions():
     """Unit check of the arithmetic in bench.make_roofline, no GPU: 1024 SIMDs at 2.4 GHz issue at most 1228.8 G
     vector instructions per second."""
-    pmc = {"valu_insts_per_launch": 6.144e9, "bytes_per_launch": 8.0e9, "source_hash": bench.source_hash(), "command": "x"}
+    pmc = {"valu_insts_per_launch": 6.144e9, "bytes_per_launch": 8.0e9, "lane_utilisation": 0.6, "source_hash": bench.source_hash(), "command": "x"}
     r = bench.make_roofline(launches=20, total_ms=200.0, rays=2.0e9, n_simds=1024, pmc=pmc, compulsory_bytes=8.0e10,
                             survey_bytes_per_ray=1800.0, frames_in_flight=1, per_kernel={})
     assert r["peak"] == 1228.8 and abs(r["achieved"] - 614.4) < 1e-9 and abs(r["frac"] - 0.5) < 1e-12
     assert abs(r["hbm"]["achieved"] - 800.0) < 1e-9 and abs(r["hbm"]["frac"] - 0.1) < 1e-12 and r["hbm"]["traffic_over_compulsory"] == 2.0
     assert r["pmc_source"]["stale"] is False and abs(r["insts_per_cycle_per_simd"] - 0.25) < 1e-12
+    assert r["lane_utilisation"] == 0.6 and abs(r["useful_frac"] - 0.3) < 1e-12
     none = bench.make_roofline(20, 200.0, 2.0e9, 1024, None, 8.0e10, None, 1, {})
     assert none["frac"] is None and none["hbm"]["frac"] is None and "survey_model" not in none

@@ -5,7 +5,7 @@ label=$1; lib=${2:-}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/depth_$label
 [ -n "$lib" ] && export PT_HIP_LIB=$lib
-timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $out -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-secondary --spp ${SPP:-16} --frames-in-flight 1 > $out.log 2>&1 || { tail -3 $out.log; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $out -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-secondary --spp ${SPP:-16} --frames-in-flight 1 ${EXTRA:-} > $out.log 2>&1 || { tail -3 $out.log; exit 1; }
 python3 - "$label" $out <<'PY'
 import csv, glob, sys
 f = glob.glob(sys.argv[2] + '/*/*kernel_trace.csv')[0]

@@ -45,10 +45,13 @@ python3 tools/pmc_summary.py $out/pmc > $out/pmc_summary.txt
 python3 tools/pmc_summary.py $out/pmc2 >> $out/pmc_summary.txt
 python3 tools/pmc_traffic.py $out/pmc --key "dragon 1920x1080 256spp depth10" -- --no-cpu-baseline --steps 3 --warmup 3 --frames-in-flight 1 > $out/traffic_dragon.json
 # the other scenes of the metric and of BASELINE's configurations: the four passes the roofline needs
-for c in cornell helmet composite; do
-  case $c in composite) extra="--width 3840 --height 2160 --spp 64"; key="composite 3840x2160 64spp depth10";; *) extra=""; key="$c 1920x1080 256spp depth10";; esac
-  PMC_MIN=1 PMC_TIMEOUT=200 bash tools/pmc_passes.sh $out/pmc_$c --scene $c $extra --steps 2 --warmup 2 --frames-in-flight 1 >> $out/pmc.log 2>&1 || { tail -5 $out/pmc.log; exit 1; }
-  python3 tools/pmc_traffic.py $out/pmc_$c --key "$key" -- --scene $c $extra --no-cpu-baseline --steps 2 --warmup 2 --frames-in-flight 1 > $out/traffic_$c.json
+for c in cornell helmet composite cube cornell512; do
+  case $c in composite) extra="--width 3840 --height 2160 --spp 64"; key="composite 3840x2160 64spp depth10";;
+             cornell512) extra="--width 512 --height 512 --spp 16"; key="cornell 512x512 16spp depth10";;
+             *) extra=""; key="$c 1920x1080 256spp depth10";; esac
+  scene=${c%512}
+  PMC_MIN=1 PMC_TIMEOUT=200 bash tools/pmc_passes.sh $out/pmc_$c --scene $scene $extra --steps 2 --warmup 2 --frames-in-flight 1 >> $out/pmc.log 2>&1 || { tail -5 $out/pmc.log; exit 1; }
+  python3 tools/pmc_traffic.py $out/pmc_$c --key "$key" -- --scene $scene $extra --no-cpu-baseline --steps 2 --warmup 2 --frames-in-flight 1 > $out/traffic_$c.json
   python3 tools/pmc_summary.py $out/pmc_$c > $out/pmc_summary_$c.txt
 done
 echo done
