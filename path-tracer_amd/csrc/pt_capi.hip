@@ -112,7 +112,9 @@ int pt_ctx_create(int device_id, void* hip_stream, PtContext** out)
 #endif
     }
     if (const char* e = getenv("PT_HIP_SCHED_MIN_RAYS")) c->sched_min_rays = (uint32_t)strtoul(e, nullptr, 10);
+#ifdef PT_EXPERIMENTAL
     if (const char* e = getenv("PT_HIP_POOL_MIN_RAYS")) c->pool_min_rays = (uint32_t)strtoul(e, nullptr, 10);
+#endif
     if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
     else {
         hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);

@@ -1188,7 +1188,12 @@ extern "C" int pt_accum_allreduce(PtContext* const* ctxs, void* const* accum, ui
 {
     PT_REQUIRE(ctxs && accum && n >= 1 && n <= kMaxPeers, "1 to 16 contexts");
     for (uint32_t r = 0; r < n; ++r) PT_REQUIRE(ctxs[r] && accum[r], "null context or image");
-    for (uint32_t r = 0; r < n; ++r) for (uint32_t k = 0; k < r; ++k) PT_REQUIRE(accum[r] != accum[k], "two contexts share one image");
+    // images of contexts on one device must not overlap (device addresses of different GPUs are not comparable)
+    for (uint32_t r = 0; r < n; ++r) for (uint32_t k = 0; k < r; ++k) {
+        if (ctxs[r]->device != ctxs[k]->device) continue;
+        const uintptr_t a = (uintptr_t)accum[r], b = (uintptr_t)accum[k], bytes = (uintptr_t)n_pixels * sizeof(float4);
+        PT_REQUIRE(a != b && (a < b ? b - a : a - b) >= bytes, "two contexts' images overlap");
+    }
     if (n == 1 || n_pixels == 0) return PT_OK;
     // peer access, both directions, once per pair of distinct devices
     for (uint32_t r = 0; r < n; ++r) {
@@ -1214,8 +1219,10 @@ extern "C" int pt_accum_allreduce(PtContext* const* ctxs, void* const* accum, ui
         if ((e = hipSetDevice(ctxs[r]->device)) != hipSuccess) return fail(e, "hipSetDevice");
         int rc = pt_lanes_join(ctxs[r]);
         if (rc) { cleanup(); return rc; }
-        if ((e = hipEventCreateWithFlags(&ev[r], hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreate");
-        if ((e = hipEventCreateWithFlags(&ev[n + r], hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreate");
+        // recorded with a release to system scope: what this GPU wrote (its image, then its slice of the sum) is visible
+        // to the peers that pass the wait, whatever the platform's default event scope is
+        if ((e = hipEventCreateWithFlags(&ev[r], hipEventDisableTiming | hipEventReleaseToSystem)) != hipSuccess) return fail(e, "hipEventCreate");
+        if ((e = hipEventCreateWithFlags(&ev[n + r], hipEventDisableTiming | hipEventReleaseToSystem)) != hipSuccess) return fail(e, "hipEventCreate");
         if ((e = hipEventRecord(ev[r], ctxs[r]->stream)) != hipSuccess) return fail(e, "hipEventRecord");
     }
     // ... before anyone reads it: GPU r sums slice r

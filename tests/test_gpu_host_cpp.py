@@ -102,9 +102,12 @@ def test_accum_allreduce_is_deterministic_and_complete(cornell):
     """pt_accum_allreduce through the C ABI: four contexts with different images; afterwards all four hold
     the same bits, the sum in context order (checked against numpy adding in that order), also for a
     pixel count that does not divide by the number of contexts, and a second call sums again."""
+    import torch
     from pt_amd import hip
     n, n_pixels = 4, 1000 * 7 + 3
-    ctxs = [hip.Context(0) for _ in range(n)]
+    # distinct devices where the box has them (real peer access over xGMI); on a one-GPU box the contexts share device 0
+    n_dev = torch.cuda.device_count()
+    ctxs = [hip.Context(k % n_dev) for k in range(n)]
     try:
         rng = np.random.default_rng(5)
         imgs = [rng.uniform(0, 4, size=(n_pixels, 4)).astype(np.float32) for _ in range(n)]
@@ -122,8 +125,13 @@ def test_accum_allreduce_is_deterministic_and_complete(cornell):
             want2 += want
         for c, p in zip(ctxs, ptrs):
             assert np.array_equal(c.download(p, n_pixels * 16, np.float32).reshape(n_pixels, 4), want2)
-        with pytest.raises(hip.PtError):
-            hip.accum_allreduce(ctxs[:2], [ptrs[0], ptrs[0]], n_pixels)
+        same_dev = [k for k in range(n) if k % n_dev == 0][:2]
+        if len(same_dev) == 2:
+            two = [ctxs[k] for k in same_dev]
+            with pytest.raises(hip.PtError):
+                hip.accum_allreduce(two, [ptrs[same_dev[0]], ptrs[same_dev[0]]], n_pixels)
+            with pytest.raises(hip.PtError):          # images that overlap without being the same pointer
+                hip.accum_allreduce(two, [ptrs[same_dev[0]], ptrs[same_dev[0]] + 64], n_pixels)
     finally:
         for c in ctxs:
             c.close()

@@ -5,7 +5,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-prefix = sys.argv[1] if len(sys.argv) > 1 else "r02_v4"
+prefix = sys.argv[1] if len(sys.argv) > 1 else "r03_v2"
 
 
 def line(name):
@@ -22,7 +22,7 @@ def gpu_row(label, j):
     r = j["roofline"]
     sm = r.get("survey_model")
     b = f"{sm['bytes_per_ray']:.0f} B (model: {sm['modelled_gbs'] / 8000:.2f} × 8 TB/s — not a bound, DESIGN §4)" if sm else "—"
-    h = f"{r['hbm']['frac']:.2f} measured (VALU issue {r['frac']:.2f})" if r.get("frac") else "not collected (PMC passes exist for the dragon workload)"
+    h = f"{r['hbm']['frac']:.2f} measured (VALU issue {r['frac']:.2f}, lanes {r['lane_utilisation']:.2f}, useful {r['useful_frac']:.2f})" if r.get("frac") else "not collected"
     return f"| {label} | HIP | 1 | {j['value'] / 1e9:.2f} G | {j['paths_per_s'] / 1e9:.2f} G | {b} | {h} |"
 
 
