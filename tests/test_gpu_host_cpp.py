@@ -135,3 +135,31 @@ def test_accum_allreduce_is_deterministic_and_complete(cornell):
     finally:
         for c in ctxs:
             c.close()
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_rehearsal_on_one_gpu(tmp_path):
+    """`python bench.py --gpus 2` with no launcher: the command starts its two ranks itself (here both on the box's one
+    GPU, all-reduce over gloo: PT_BENCH_REHEARSAL=1) and prints one line that describes what ran: two ranks, every
+    frame of both in the reduced image, twice the paths of one rank."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, PT_BENCH_REHEARSAL="1")
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--scene", "cornell", "--width", "320",
+           "--height", "180", "--spp", "16", "--frames-in-flight", "1", "--no-cpu-baseline", "--no-secondary"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, p.stdout[-2000:]
+    j = json.loads(lines[0])
+    par = j["config"]["parallelism"]
+    assert j["n_gpus"] == 2 and par["world_size"] == 2 and par["backend"] == "gloo" and j["scaling"] == "weak"
+    assert j["frames_accumulated"] == 4 and par["steps_total"] == 4
+    assert [r["rank"] for r in par["ranks"]] == [0, 1] and all(r["rehearsal_shared_device"] for r in par["ranks"])
+    assert abs(j["paths_per_s"] * j["time_to_image_s"] - 4 * 320 * 180 * 16) < 1.0
+    # asking for more ranks than the launcher provides is refused, not silently reduced
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    q = subprocess.run(cmd, env=env2, capture_output=True, text=True, timeout=120)
+    assert q.returncode != 0 and "WORLD_SIZE=1" in q.stderr
