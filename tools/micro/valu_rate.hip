@@ -8,6 +8,9 @@
 // v_and_or_b32, v_bfi_b32, v_perm_b32, v_bfe_u32), v_fmac_f32 and v_pk_fma_f32 stay at 0.22-0.24
 // however many waves share the SIMD; v_rcp_f32 0.12.  A stream of nothing but v_cndmask_b32_e32 (implicit
 // vcc) drops to 0.044, but mixed with other instructions the e32 and e64 forms cost the same.
+// Sub-dword operand forms (`valu_rate s`): v_or/and/mov/lshlrev_b32_sdwa and v_add_f32_sdwa with a byte or word
+// selected, v_mov_b32_dpp, v_cvt_f32_fp8, v_cvt_pk_f32_fp8 and v_cvt_scalef32_pk_f32_fp8 all issue at 0.22-0.23: a byte
+// cannot be brought into a float register at the full rate by any of them.
 // build: hipcc --offload-arch=gfx950 -O3 -o valu_rate valu_rate.hip ; run on the GPU box
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -94,6 +97,16 @@ __global__ void __launch_bounds__(256) k_rate(float* out, float a, float b, uint
             if (KIND == 67) asm volatile("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]\n v_fma_f32 %0, %0, %2, %3" : "=v"(x[i]) : "v"(word), "v"(a), "v"(b));
             if (KIND == 68) asm volatile("v_cvt_f32_ubyte1 %0, %1\n v_fma_f32 %0, %0, %2, %3\n v_fma_f32 %0, %0, %2, %3" : "=v"(x[i]) : "v"(word), "v"(a), "v"(b));
             if (KIND == 69) asm volatile("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(x[i]) : "v"(word), "v"(a), "v"(b));
+            if (KIND == 70) asm volatile("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(x[i]) : "v"(a), "v"(word));
+            if (KIND == 71) asm volatile("v_add_f32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(x[i]) : "v"(a), "v"(word));
+            if (KIND == 72) asm volatile("v_cvt_pk_f32_fp8 %0, %1" : "=v"(y[i & 7]) : "v"(word));
+            if (KIND == 73) asm volatile("v_cvt_scalef32_pk_f32_fp8 %0, %1, %2" : "=v"(y[i & 7]) : "v"(word), "v"(a));
+            if (KIND == 74) asm volatile("v_cvt_f32_fp8 %0, %1" : "=v"(x[i]) : "v"(word));
+            if (KIND == 75) asm volatile("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n v_fma_f32 %0, %0, %1, %3\n v_fma_f32 %0, %0, %1, %3" : "=v"(x[i]) : "v"(a), "v"(word), "v"(b));
+            if (KIND == 76) asm volatile("v_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(x[i]) : "v"(a));
+            if (KIND == 77) asm volatile("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(x[i]) : "v"(a), "v"(word));
+            if (KIND == 78) asm volatile("v_mov_b32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3" : "=v"(x[i]) : "v"(word));
+            if (KIND == 79) asm volatile("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(x[i]) : "v"(word), "v"(word));
         }
     }
     const unsigned long long c1 = clock64();
@@ -135,6 +148,23 @@ int main(int argc, char** argv)
     hipDeviceProp_t p; CHECK(hipGetDeviceProperties(&p, 0));
     const int cus = p.multiProcessorCount;
     printf("%s, %d CUs\n", p.gcnArchName, cus);
+    if (argc > 1 && argv[1][0] == 's') {       // sub-dword (SDWA) operand forms, fp8 conversions
+        if (run<0>("v_fma_f32", cus)) return 1;
+        if (run<23>("v_or_b32", cus)) return 1;
+        if (run<2>("v_cvt_f32_ubyte1", cus)) return 1;
+        if (run<70>("v_or_b32_sdwa byte", cus)) return 1;
+        if (run<77>("v_and_b32_sdwa byte", cus)) return 1;
+        if (run<78>("v_mov_b32_sdwa byte", cus)) return 1;
+        if (run<79>("v_lshlrev_b32_sdwa", cus)) return 1;
+        if (run<71>("v_add_f32_sdwa word", cus)) return 1;
+        if (run<72>("v_cvt_pk_f32_fp8", cus)) return 1;
+        if (run<73>("v_cvt_scalef32_pk_f32_fp8", cus)) return 1;
+        if (run<74>("v_cvt_f32_fp8", cus)) return 1;
+        if (run<76>("v_mov_b32_dpp", cus)) return 1;
+        if (run<75>("or_sdwa+fma+fma (x3 instr)", cus)) return 1;
+        if (run<68>("cvt+fma+fma (x3 instr)", cus)) return 1;
+        return 0;
+    }
     if (argc > 1 && argv[1][0] == 'm') {       // the mixed-precision and 16-bit forms only
         if (run<0>("v_fma_f32", cus)) return 1;
         if (run<2>("v_cvt_f32_ubyte1", cus)) return 1;
