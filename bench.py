@@ -220,7 +220,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=256,
-                    help="samples per pixel per step (one pt_trace call). The whole step is resident at once (160 bytes of queues "
+                    help="samples per pixel per step (one pt_trace call). The whole step is resident at once (128 bytes of queues "
                          "and records per path); every bounce level is one launch whose ramp-down is a fixed cost, so throughput rises "
                          "with the step. If the queues do not fit, the step is halved until they do")
     ap.add_argument("--total-spp", type=int, default=0,

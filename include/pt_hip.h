@@ -254,7 +254,7 @@ int pt_ctx_set_profiling(PtContext* ctx, int enabled);
 int pt_trace_profile(PtContext* ctx, PtTraceProfile* out);
 
 /* Upper bound on paths resident at once per frame in flight, in [64, 2^31) (default 1<<27, about
- * 21 GB of queues when reached; queues are sized by the largest chunk actually traced); a larger
+ * 17 GB of queues when reached; queues are sized by the largest chunk actually traced); a larger
  * frame is rendered in pixel chunks. */
 int pt_ctx_set_max_paths(PtContext* ctx, uint64_t max_paths);
 
@@ -273,6 +273,15 @@ int pt_accum_resolve(PtContext* ctx, const float* accum_sum_dev, uint32_t n_pixe
  * frames in flight and for the other contexts; pt_sync a context before reading its image on the host.
  * n <= 16; contexts may share a device (rehearsal on one GPU); devices must have peer access. */
 int pt_accum_allreduce(PtContext* const* ctxs, void* const* accum_sum_dev, uint32_t n, uint32_t n_pixels);
+
+/* No counterpart in the reference: a self-test of the library's arithmetic on the GPU in use.  The tracing kernels
+ * compute 1/x, sqrt(x), x/pi and byte/255 with the hardware approximations and one residual correction instead of
+ * the IEEE expansions, and divide path indices by samples-per-pixel and image width with a multiplier; results
+ * must have the bits of the correctly rounded operations (what a CPU computes for the GLSL's `/` and sqrt).
+ * This call compares them over every binary32 pattern (every byte; eighteen divisors and every third index below
+ * 2^31) and returns the number of differing results: mismatches[0..4] = reciprocal, square root, x/pi, byte/255,
+ * integer division.  All five must be zero.  Synchronous, about a second. */
+int pt_selftest_arith(PtContext* ctx, uint64_t mismatches[5]);
 
 #ifdef __cplusplus
 }

@@ -24,6 +24,52 @@ __device__ __forceinline__ void pt_stream_store(float4* p, const float4 v)
     __builtin_nontemporal_store(w, (pt_v4f*)p);
 }
 
+// 1 / x and sqrt(x) with the bits of the correctly rounded operations, in a third of the instructions of the
+// compiler's IEEE expansions (v_div_scale x 2, v_rcp, six fmas, v_div_fmas, v_div_fixup): the hardware
+// approximation and one residual correction, r = rcp(x), r += r * fma(-x, r, 1); s = x * rsq(x), s += (rsq(x) / 2) *
+// fma(-s, s, x).  tools/micro/rcp_exact.hip compares both with the IEEE forms over every binary32 pattern: not one
+// differs for 2^-126 <= |x| <= 2^126 (reciprocal) and 2^-100 <= x <= 2^100 (root).  Outside 2^-100 .. 2^100
+// (zeros, subnormals, infinities, NaNs) the whole wave takes the IEEE form, which happens only with rays or
+// triangles that are not finite or degenerate.
+#define PT_EXACT_LO 0x1p-100f
+#define PT_EXACT_HI 0x1p+100f
+__device__ __forceinline__ float pt_rcp_core(float x)
+{
+    const float r = __builtin_amdgcn_rcpf(x);
+    return PT_FMA(PT_FMA(-x, r, 1.0f), r, r);
+}
+__device__ __forceinline__ float pt_rcp(float x)
+{
+    const float ax = fabsf(x);
+    if (__ballot(!(ax >= PT_EXACT_LO && ax <= PT_EXACT_HI)) != 0ull) return 1.0f / x;
+    return pt_rcp_core(x);
+}
+__device__ __forceinline__ float pt_sqrt(float x)
+{
+    if (__ballot(!(x >= PT_EXACT_LO && x <= PT_EXACT_HI)) != 0ull) return sqrtf(x);
+    const float y = __builtin_amdgcn_rsqf(x);
+    const float s = x * y, h = 0.5f * y;
+    return PT_FMA(PT_FMA(-s, s, x), h, s);
+}
+
+// x / c for the two constant divisors of the shaders (pi in closest_hit.rchit:73,80, 255 in the UNORM8 texel):
+// q = x * RN(1 / c), q += RN(1 / c) * fma(-c, q, x).  Over every binary32 pattern (tools/micro/rcp_exact.hip) the
+// result has the bits of the division for 2^-100 <= |x| <= 2^100 and for +0; a texel byte is one of 256 such values.
+__device__ __forceinline__ float pt_div_pi(float x)
+{
+    constexpr float c = 3.14159265f, rc = 1.0f / c;
+    const float ax = fabsf(x);
+    if (__ballot(!((ax >= PT_EXACT_LO && ax <= PT_EXACT_HI) || __float_as_uint(x) == 0u)) != 0ull) return x / c;
+    const float q = x * rc;
+    return PT_FMA(PT_FMA(-c, q, x), rc, q);
+}
+__device__ __forceinline__ float pt_unorm8(uint32_t byte)
+{
+    constexpr float c = 255.0f, rc = 1.0f / c;
+    const float x = (float)byte, q = x * rc;
+    return PT_FMA(PT_FMA(-c, q, x), rc, q);
+}
+
 struct PtRaySpace {
     float ox, oy, oz, dx, dy, dz;
     float ix, iy, iz;        // 1 / d with |d| clamped away from zero
@@ -35,11 +81,18 @@ __device__ __forceinline__ float pt_safe_rcp(float d)
     float s = fabsf(d) > PT_DIR_EPS ? d : copysignf(PT_DIR_EPS, d);
     return 1.0f / s;
 }
+__device__ __forceinline__ float pt_dir_clamp(float d) { return fabsf(d) > PT_DIR_EPS ? d : copysignf(PT_DIR_EPS, d); }
 
 __device__ __forceinline__ void pt_ray_space_init(PtRaySpace& r, float ox, float oy, float oz, float dx, float dy, float dz)
 {
     r.ox = ox; r.oy = oy; r.oz = oz; r.dx = dx; r.dy = dy; r.dz = dz;
-    r.ix = pt_safe_rcp(dx); r.iy = pt_safe_rcp(dy); r.iz = pt_safe_rcp(dz);
+    // the three divisors are at least 2^-80 in magnitude: one test of the largest decides for all three
+    const float sx = pt_dir_clamp(dx), sy = pt_dir_clamp(dy), sz = pt_dir_clamp(dz);
+    if (__ballot(!(fmaxf(fmaxf(fabsf(sx), fabsf(sy)), fabsf(sz)) <= PT_EXACT_HI)) != 0ull) {
+        r.ix = 1.0f / sx; r.iy = 1.0f / sy; r.iz = 1.0f / sz;
+    } else {
+        r.ix = pt_rcp_core(sx); r.iy = pt_rcp_core(sy); r.iz = pt_rcp_core(sz);
+    }
     r.oox = ox * r.ix; r.ooy = oy * r.iy; r.ooz = oz * r.iz;
 }
 
@@ -98,7 +151,7 @@ __device__ __forceinline__ bool pt_tri_test(const PtRaySpace& r, float delta,
     if (det == 0.0f) return false;
     float Az = Sz * Akz, Bz = Sz * Bkz, Cz = Sz * Ckz;
     float T = PT_FMA(W, Cz, PT_FMA(V, Bz, U * Az));
-    float rcp = 1.0f / det;
+    float rcp = pt_rcp(det);
     t = T * rcp; u = V * rcp; v = W * rcp;
     float tn, tf;
     pt_slab(r, fminf(fminf(v0x, v1x), v2x) - delta, fminf(fminf(v0y, v1y), v2y) - delta, fminf(fminf(v0z, v1z), v2z) - delta,
@@ -411,6 +464,6 @@ __device__ __forceinline__ void pt_sincos(float x, float& s_out, float& c_out)
 __device__ __forceinline__ void pt_normalize(float& x, float& y, float& z)
 {
     float len2 = PT_FMA(z, z, PT_FMA(y, y, x * x));
-    float inv = 1.0f / sqrtf(len2);
+    float inv = pt_rcp(pt_sqrt(len2));
     x *= inv; y *= inv; z *= inv;
 }

@@ -8,9 +8,9 @@
 //                bookkeeping of ray_gen.rgen:67-68; survivors are compacted into the next queue
 //   k_accumulate shaders/ray_gen.rgen:71-87   per-pixel sum over samples, running mean / sum
 //
-// Path state lives in four float4 streams per queue slot (ping-pong between bounces):
-//   q0 = (origin.xyz, -)                         q1 = (direction.xyz, -)            read by traversal
-//   q2 = (currentWeight.rgb, bits(seed))         q3 = (hitValue.rgb, bits(path id)) read by shading
+// Path state lives in four float4 streams per queue slot:
+//   q0 = (origin.xyz, -)                         q1 = (direction.xyz, -)            read by traversal, one buffer each
+//   q2 = (currentWeight.rgb, bits(seed))         q3 = (hitValue.rgb, bits(path id)) read by shading, ping-pong between bounces
 // so every lane moves 16 bytes per access and a wave moves 1 KiB per instruction.  The "path id" is the
 // slot of the path's final radiance, laid out [pixel of the chunk][sample].  The streams come into being
 // with the survivors of bounce 0; bounce 0 itself reads none of them.
@@ -116,9 +116,24 @@ struct PtCameraArg { float m[32]; };
 // What bounce 0 needs to know about a path without any stored state: ray_gen.rgen:21-47 is a pure
 // function of the path index, so the primary ray is computed where it is traced and the seed where
 // it is first used; no generation pass writes 32 bytes per path for the next two kernels to read back.
+// Division of a 31-bit index by a divisor fixed for the launch (samples per pixel, image width): with
+// m = floor(2^32 (2^s - d) / d) + 1, s = ceil(log2 d), floor(n / d) = (mulhi(m, n) + n) >> s for every n < 2^31
+// (Granlund and Montgomery's round-up multiplier; the sum stays below 2^32).  Three instructions where the
+// compiler's expansion of a 32-bit division takes about thirty.
+struct PtDivisor { uint32_t d, m, s; };
+inline PtDivisor pt_divisor(uint32_t d)
+{
+    PtDivisor r; r.d = d; r.s = 0;
+    while ((1ull << r.s) < d) ++r.s;
+    r.m = (uint32_t)((((1ull << r.s) - d) << 32) / d + 1ull);
+    return r;
+}
+__device__ __forceinline__ uint32_t pt_div(uint32_t n, const PtDivisor& D) { return (__umulhi(D.m, n) + n) >> D.s; }
+
 struct PtPrimaryArg {
     PtCameraArg camera;     // viewInverse, projInverse; by value: no copy to wait for
     uint32_t n_paths, pixel0, spp, W, H, frame, seed_mode;
+    PtDivisor by_spp, by_W; // path indices and pixel indices are below 2^31
 };
 
 // Path index of a queue slot at bounce 0 (inverse of slot_of_path); s = shard of the slot.
@@ -131,8 +146,8 @@ __device__ __forceinline__ uint32_t path_of_slot(uint32_t slot, uint32_t s, uint
 // ray_gen.rgen:21-31: origin and direction of the primary ray of path q
 __device__ __forceinline__ void pt_primary_ray(const PtPrimaryArg& P, uint32_t q, float& ox, float& oy, float& oz, float& rx, float& ry, float& rz)
 {
-    const uint32_t pixel = P.pixel0 + q / P.spp;
-    const uint32_t px = pixel % P.W, py = pixel / P.W;
+    const uint32_t pixel = P.pixel0 + pt_div(q, P.by_spp);
+    const uint32_t py = pt_div(pixel, P.by_W), px = pixel - py * P.W;
     const float* VI = P.camera.m; const float* PI = P.camera.m + 16;
     float uvx = ((float)px + 0.5f) / (float)P.W;
     float uvy = ((float)py + 0.5f) / (float)P.H;
@@ -151,13 +166,12 @@ __device__ __forceinline__ void pt_primary_ray(const PtPrimaryArg& P, uint32_t q
 // the samples of a pixel sit in neighbouring lanes when their paths end, so they are written together
 __device__ __forceinline__ void pt_primary_seed(const PtPrimaryArg& P, uint32_t q, uint32_t& seed, uint32_t& result_slot)
 {
-    const uint32_t in_chunk = q / P.spp, s = q % P.spp, pixel = P.pixel0 + in_chunk;
-    const uint32_t px = pixel % P.W, py = pixel / P.W;
+    const uint32_t in_chunk = pt_div(q, P.by_spp), s = q - in_chunk * P.spp, pixel = P.pixel0 + in_chunk;
     // the reference reads the clock once per sample inside a pixel's loop, so successive samples see successive
     // values; here a pixel's samples are lanes that read the (wave-uniform) clock together, and the sample index
     // is added so that they still differ
     const uint32_t v1 = P.seed_mode == PT_SEED_CLOCK ? (uint32_t)clock64() + s : P.frame * P.spp + s;
-    seed = pt_tea(py * P.W + px, v1);
+    seed = pt_tea(pixel, v1);                  // gl_LaunchIDEXT.y * width + x is the pixel's index
     result_slot = q;
 }
 
@@ -316,8 +330,8 @@ __device__ __forceinline__ void pt_texture_rgb(const uint32_t* __restrict__ texe
     float out[3];
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
-        float c00 = (float)((t00 >> (8 * ch)) & 255u) / 255.0f, c10 = (float)((t10 >> (8 * ch)) & 255u) / 255.0f;
-        float c01 = (float)((t01 >> (8 * ch)) & 255u) / 255.0f, c11 = (float)((t11 >> (8 * ch)) & 255u) / 255.0f;
+        float c00 = pt_unorm8((t00 >> (8 * ch)) & 255u), c10 = pt_unorm8((t10 >> (8 * ch)) & 255u);
+        float c01 = pt_unorm8((t01 >> (8 * ch)) & 255u), c11 = pt_unorm8((t11 >> (8 * ch)) & 255u);
         float r0 = PT_FMA(a, c10 - c00, c00);
         float r1 = PT_FMA(a, c11 - c01, c01);
         out[ch] = PT_FMA(bb, r1 - r0, r0);
@@ -355,7 +369,6 @@ __device__ __forceinline__ void shade_batch(const PtShadeArgs& S, const PtDevSha
                                             const float4 cw, float4 hv)
 {
     const uint32_t lane = threadIdx.x & 63;
-    const float PI_F = 3.14159265f;
     // Which paths go on is known from the hit alone, so the batch claims its slots in the next queue
     // first and the atomic's round trip overlaps the gathers below.
     const bool alive = valid && h.instance != 0xFFFFFFFFu && S.depth + 1 < S.max_depth;
@@ -406,10 +419,10 @@ __device__ __forceinline__ void shade_batch(const PtShadeArgs& S, const PtDevSha
             // CreateCoordinateSystem, sampling.glsl:53-65
             float Tx, Ty, Tz;
             if (fabsf(Nx) > fabsf(Ny)) {
-                float inv = 1.0f / sqrtf(PT_FMA(Nz, Nz, Nx * Nx));
+                float inv = pt_rcp(pt_sqrt(PT_FMA(Nz, Nz, Nx * Nx)));
                 Tx = Nz * inv; Ty = 0.0f; Tz = -Nx * inv;
             } else {
-                float inv = 1.0f / sqrtf(PT_FMA(Nz, Nz, Ny * Ny));
+                float inv = pt_rcp(pt_sqrt(PT_FMA(Nz, Nz, Ny * Ny)));
                 Tx = 0.0f; Ty = -Nz * inv; Tz = Ny * inv;
             }
             float Bx = PT_FMA(Ny, Tz, -(Nz * Ty));
@@ -419,16 +432,16 @@ __device__ __forceinline__ void shade_batch(const PtShadeArgs& S, const PtDevSha
             uint32_t seed = seed_in;
             float r1 = pt_random(seed);
             float r2 = pt_random(seed);
-            float sq = sqrtf(r1);
+            float sq = pt_sqrt(r1);
             float sn, cs;
             pt_sincos(6.28318548f * r2, sn, cs);
-            float lx = cs * sq, ly = sn * sq, lz = sqrtf(1.0f - r1);
+            float lx = cs * sq, ly = sn * sq, lz = pt_sqrt(1.0f - r1);
             float Dx = PT_FMA(lz, Nx, PT_FMA(ly, Bx, lx * Tx));
             float Dy = PT_FMA(lz, Ny, PT_FMA(ly, By, lx * Ty));
             float Dz = PT_FMA(lz, Nz, PT_FMA(ly, Bz, lx * Tz));
             // :71-85
             float cosTheta = PT_FMA(Dz, Nz, PT_FMA(Dy, Ny, Dx * Nx));
-            float pdf = cosTheta / PI_F;
+            float pdf = pt_div_pi(cosTheta);
             const float4 alb = I.albedo;
             float ar = alb.x, ag = alb.y, ab = alb.z;
             if (__float_as_uint(alb.w)) {
@@ -437,7 +450,7 @@ __device__ __forceinline__ void shade_batch(const PtShadeArgs& S, const PtDevSha
                 pt_texture_rgb((const uint32_t*)ptr_from(tex.x, tex.y), (int)__float_as_uint(tex.z), (int)__float_as_uint(tex.w), tu, tv, tr, tg, tbb);
                 ar = ar * tr; ag = ag * tg; ab = ab * tbb;
             }
-            float wr = (ar / PI_F) * cosTheta / pdf, wg = (ag / PI_F) * cosTheta / pdf, wb = (ab / PI_F) * cosTheta / pdf;
+            float wr = pt_div_pi(ar) * cosTheta / pdf, wg = pt_div_pi(ag) * cosTheta / pdf, wb = pt_div_pi(ab) * cosTheta / pdf;
             // ray_gen.rgen:67-68
             const float4 em = I.emissive;
             hv.x = PT_FMA(em.x, cw.x, hv.x);
@@ -594,7 +607,7 @@ k_primary(PtTlasView tl, PtShadeArgs A, float tmin, float tmax, int* __restrict_
         if (valid) {
             const uint32_t q = path_of_slot(i, shard, A.shard_cap);
             if constexpr (SHARED) {
-                h = pixel_hits[q / A.primary.spp];     // the lanes of a wave hold a pixel's samples: a broadcast
+                h = pixel_hits[pt_div(q, A.primary.by_spp)];     // the lanes of a wave hold a pixel's samples: a broadcast
             } else {
                 float ox, oy, oz, dx, dy, dz;
                 pt_primary_ray(A.primary, q, ox, oy, oz, dx, dy, dz);
@@ -754,7 +767,9 @@ int ensure_workspace(PtContext* ctx, PtLane& l, uint64_t paths, uint64_t pixels,
         l.shard_cap_wanted = cap;
         const uint64_t slots = cap * kShards;
         l.rays_only = rays_only;
-        for (int a = 0; a < (rays_only ? 1 : 2); ++a) for (int k = 0; k < (rays_only ? 2 : 4); ++k) PT_HIP_CHECK(hipMalloc((void**)&l.q[a][k], sizeof(float4) * slots));
+        // The ray streams (0, 1) exist once: traversal has read a level's rays before shading writes the next level's
+        // over them.  The shading streams (2, 3) are read and written by the same pass and ping-pong.
+        for (int a = 0; a < (rays_only ? 1 : 2); ++a) for (int k = (a == 1 ? 2 : 0); k < (rays_only ? 2 : 4); ++k) PT_HIP_CHECK(hipMalloc((void**)&l.q[a][k], sizeof(float4) * slots));
         if (!rays_only) {
             PT_HIP_CHECK(hipMalloc((void**)&l.hits, sizeof(PtHit) * slots));
             PT_HIP_CHECK(hipMalloc((void**)&l.path_result, sizeof(float4) * slots));
@@ -993,6 +1008,7 @@ int pt_trace(PtContext* ctx, const PtTlas* tlas, const float camera[32], uint32_
     PtPrimaryArg primary;
     memcpy(primary.camera.m, camera, sizeof primary.camera.m);
     primary.spp = spp; primary.W = width; primary.H = height; primary.frame = frame; primary.seed_mode = seed_mode;
+    primary.by_spp = pt_divisor(spp); primary.by_W = pt_divisor(width);
     const int blocks_i = persistent_blocks(ctx, (const void*)k_intersect<false>);
 #ifdef PT_EXPERIMENTAL
     const int blocks_pool = pool_blocks(ctx, (const void*)k_intersect_pool<false>);
@@ -1036,7 +1052,7 @@ int pt_trace(PtContext* ctx, const PtTlas* tlas, const float camera[32], uint32_
             PtShadeArgs sa;
             sa.shade_inst = tlas->shade_inst; sa.depth = d; sa.max_depth = max_depth; sa.counters = w.counters; sa.shard_cap = w.shard_cap;
             sa.q2 = w.q[a][2]; sa.q3 = w.q[a][3];
-            sa.o0 = w.q[b][0]; sa.o1 = w.q[b][1]; sa.o2 = w.q[b][2]; sa.o3 = w.q[b][3];
+            sa.o0 = w.q[0][0]; sa.o1 = w.q[0][1]; sa.o2 = w.q[b][2]; sa.o3 = w.q[b][3];
             sa.path_result = w.path_result; sa.primary = primary;
             if (d == 0) {
                 // the timed interval of bounce 0 holds its shading as well
@@ -1051,17 +1067,17 @@ int pt_trace(PtContext* ctx, const PtTlas* tlas, const float camera[32], uint32_
             } else {
 #ifdef PT_EXPERIMENTAL
                 if (ctx->traversal_mode == 3)
-                    k_intersect_pair<false><<<blocks_pair, kBlock, 0, st>>>(tv, w.counters, d, w.shard_cap, w.q[a][0], w.q[a][1],
+                    k_intersect_pair<false><<<blocks_pair, kBlock, 0, st>>>(tv, w.counters, d, w.shard_cap, w.q[0][0], w.q[0][1],
                                                                             0.001f, 10000.0f, w.hits, nullptr, w.spill);
                 else
 #endif
 #ifdef PT_EXPERIMENTAL
                 if (ctx->traversal_mode >= 4)
-                    k_intersect_pool<false><<<blocks_pool, kBlock, 0, st>>>(tv, w.counters, d, w.shard_cap, w.q[a][0], w.q[a][1],
+                    k_intersect_pool<false><<<blocks_pool, kBlock, 0, st>>>(tv, w.counters, d, w.shard_cap, w.q[0][0], w.q[0][1],
                                                                             0.001f, 10000.0f, w.hits, nullptr, w.spill, sched_threshold(ctx, d));
                 else
 #endif
-                    k_intersect<false><<<blocks_i, kBlock, 0, st>>>(tv, w.counters, d, w.shard_cap, w.q[a][0], w.q[a][1],
+                    k_intersect<false><<<blocks_i, kBlock, 0, st>>>(tv, w.counters, d, w.shard_cap, w.q[0][0], w.q[0][1],
                                                                     0.001f, 10000.0f, w.hits, nullptr, w.spill, sched_threshold(ctx, d));
                 if (ev_stop) PT_HIP_CHECK(hipEventRecord(ev_stop, st));
                 k_shade<<<blocks_s, kBlock, 0, st>>>(sa, w.hits);
@@ -1258,6 +1274,69 @@ extern "C" int pt_accum_allreduce(PtContext* const* ctxs, void* const* accum, ui
     e = hipGetLastError();
     if (e != hipSuccess) return fail(e, "kernel launch");
     cleanup();
+    return PT_OK;
+}
+
+// ---- self-test of the short arithmetic forms ------------------------------------------------------
+// pt_rcp, pt_sqrt, pt_div_pi and pt_unorm8 replace IEEE divisions and square roots on the strength of an exhaustive
+// comparison; this entry point repeats that comparison on the GPU in use: every binary32 pattern through the public
+// forms (guards included) against the compiler's IEEE expansions, every byte through pt_unorm8, and pt_div against the
+// 32-bit division for a set of divisors and every third index below 2^31.
+namespace {
+__global__ void k_selftest_float(unsigned long long* __restrict__ bad)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned long long n_rcp = 0, n_sqrt = 0, n_pi = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (1ull << 32); i += stride) {
+        const float x = __uint_as_float((uint32_t)i);
+        const float a = pt_rcp(x), a0 = 1.0f / x;
+        const float b = pt_sqrt(x), b0 = sqrtf(x);
+        const float c = pt_div_pi(x), c0 = x / 3.14159265f;
+        n_rcp += (__float_as_uint(a) != __float_as_uint(a0) && !(a != a && a0 != a0)) ? 1u : 0u;
+        n_sqrt += (__float_as_uint(b) != __float_as_uint(b0) && !(b != b && b0 != b0)) ? 1u : 0u;
+        n_pi += (__float_as_uint(c) != __float_as_uint(c0) && !(c != c && c0 != c0)) ? 1u : 0u;
+    }
+    if (n_rcp) atomicAdd(&bad[0], n_rcp);
+    if (n_sqrt) atomicAdd(&bad[1], n_sqrt);
+    if (n_pi) atomicAdd(&bad[2], n_pi);
+    if (blockIdx.x == 0 && threadIdx.x < 256) {
+        const float t = pt_unorm8(threadIdx.x), t0 = (float)threadIdx.x / 255.0f;
+        if (__float_as_uint(t) != __float_as_uint(t0)) atomicAdd(&bad[3], 1ull);
+    }
+}
+__global__ void k_selftest_div(PtDivisor D, unsigned long long* __restrict__ bad)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x * 3u;
+    unsigned long long n = 0;
+    for (uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 3u; i < (1ull << 31); i += stride)
+        n += pt_div((uint32_t)i, D) != (uint32_t)i / D.d ? 1u : 0u;
+    // the ends of the range, whatever the stride
+    if (blockIdx.x == 0 && threadIdx.x < 64) {
+        const uint32_t e = 0x7FFFFFFFu - threadIdx.x;
+        n += pt_div(e, D) != e / D.d ? 1u : 0u;
+        n += pt_div(threadIdx.x, D) != threadIdx.x / D.d ? 1u : 0u;
+    }
+    if (n) atomicAdd(&bad[4], n);
+}
+} // namespace
+
+extern "C" int pt_selftest_arith(PtContext* ctx, uint64_t mismatches[5])
+{
+    PT_REQUIRE(ctx && mismatches, "null argument");
+    PT_HIP_CHECK(hipSetDevice(ctx->device));
+    unsigned long long* d = nullptr;
+    PT_HIP_CHECK(hipMalloc((void**)&d, sizeof(unsigned long long) * 5));
+    hipError_t e = hipMemsetAsync(d, 0, sizeof(unsigned long long) * 5, ctx->stream);
+    if (e == hipSuccess) {
+        k_selftest_float<<<ctx->num_cus * 8, kBlock, 0, ctx->stream>>>(d);
+        const uint32_t divisors[] = { 1u, 2u, 3u, 5u, 7u, 16u, 25u, 64u, 255u, 256u, 641u, 1000u, 1080u, 1920u, 3840u, 65535u, 65536u, 0x7FFFFFFFu };
+        for (uint32_t dv : divisors) k_selftest_div<<<ctx->num_cus * 8, kBlock, 0, ctx->stream>>>(pt_divisor(dv), d);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(mismatches, d, sizeof(unsigned long long) * 5, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) { pt_set_error("pt_selftest_arith: %s", hipGetErrorString(e)); return PT_ERROR_HIP; }
     return PT_OK;
 }
 

@@ -63,6 +63,7 @@ SIGNATURES = {
     "pt_trace_profile": (_i, [_vp, _vp]),
     "pt_accum_resolve": (_i, [_vp, _vp, _u32, _vp, _i]),
     "pt_accum_allreduce": (_i, [_vp, _vp, _u32, _u32]),
+    "pt_selftest_arith": (_i, [_vp, _vp]),
 }
 
 _lib = None
@@ -139,6 +140,13 @@ class Context:
     def set_share_primary(self, enabled):
         """Bounce 0 traced once per pixel and shared by the pixel's samples (identical images, fewer rays traversed)."""
         _check(self.lib.pt_ctx_set_share_primary(self.h, int(enabled)))
+
+    def selftest_arith(self):
+        """pt_selftest_arith: results of the short forms of 1/x, sqrt, x/pi, byte/255 and the index division that
+        differ from the IEEE operations over all inputs, as a dict of counts (all must be 0)."""
+        out = (C.c_uint64 * 5)()
+        _check(self.lib.pt_selftest_arith(self.h, out))
+        return dict(zip(("reciprocal", "sqrt", "div_pi", "unorm8", "index_division"), (int(v) for v in out)))
 
     def close(self):
         if self.h:

@@ -7,6 +7,6 @@ for mp in $2; do for l in $1; do
 import json,sys
 j=json.loads(sys.argv[3])
 mp=int(sys.argv[2]); paths=mp if mp else 1920*1080*256
-print("lanes %s chunk %10d paths (%5.1f GB of queues): rays/s %.3e ms/step %6.2f"%(sys.argv[1],paths,int(sys.argv[1])*paths*160/1e9,j["value"],j["ms_per_step"]))
+print("lanes %s chunk %10d paths (%5.1f GB of queues): rays/s %.3e ms/step %6.2f"%(sys.argv[1],paths,int(sys.argv[1])*paths*128/1e9,j["value"],j["ms_per_step"]))
 PY
 done; done
