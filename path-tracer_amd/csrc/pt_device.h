@@ -329,11 +329,11 @@ __device__ __forceinline__ int pt_wide_step(const PtRaySpace& r, const float4* _
         ref[k] = ref_in[k];
     }
     }
+    const int nh = (tn[0] < inf ? 1 : 0) + (tn[1] < inf ? 1 : 0) + (tn[2] < inf ? 1 : 0) + (tn[3] < inf ? 1 : 0);
 #ifndef PT_NO_UNIFORM_SKIP
     // Ordering matters only where a lane has two or more children to go on with; when no lane of the wave has
     // (coherent rays near the leaves: +1.5 % on the dragon frame), the five compare-exchanges are skipped by a
     // wave-uniform branch.
-    const int nh = (tn[0] < inf ? 1 : 0) + (tn[1] < inf ? 1 : 0) + (tn[2] < inf ? 1 : 0) + (tn[3] < inf ? 1 : 0);
     if (__ballot(nh > 1) == 0ull) {
         const int r = tn[0] < inf ? ref[0] : (tn[1] < inf ? ref[1] : (tn[2] < inf ? ref[2] : ref[3]));
         return nh ? r : stk.pop();
@@ -343,6 +343,14 @@ __device__ __forceinline__ int pt_wide_step(const PtRaySpace& r, const float4* _
                          const int ra = sw ? ref[j] : ref[i], rb = sw ? ref[i] : ref[j]; tn[i] = ta; tn[j] = tb; ref[i] = ra; ref[j] = rb; }
     PT_CSWAP(0, 1) PT_CSWAP(2, 3) PT_CSWAP(0, 2) PT_CSWAP(1, 3) PT_CSWAP(1, 2)
 #undef PT_CSWAP
+    if constexpr (!F32) {
+        // The children to go on with are the nh smallest keys, at the front.  (Quantised planes are finite, so the
+        // entry distances of a node are NaN for all of its children or for none: the order is total and the count
+        // taken before the network holds after it.  The float planes of an empty child are infinite and can mix
+        // NaNs in for a ray that is not finite, so that form counts again.)
+        stk.push_far_to_near(ref[1], ref[2], ref[3], max(nh - 1, 0));
+        return nh > 0 ? ref[0] : stk.pop();
+    }
     const int m = (tn[1] < inf ? 1 : 0) + (tn[2] < inf ? 1 : 0) + (tn[3] < inf ? 1 : 0);
     stk.push_far_to_near(ref[1], ref[2], ref[3], m);
     return tn[0] < inf ? ref[0] : stk.pop();
