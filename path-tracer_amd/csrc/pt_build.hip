@@ -438,7 +438,7 @@ __global__ void k_wide_expand(const PtWide4* __restrict__ in, uint32_t n, PtWide
     PtWideF f;
     const float inf = __builtin_inff();
     for (int e = 0; e < 4; ++e) {
-        const bool empty = w.child[e] == PT_WIDE_EMPTY;
+        const bool empty = pt_wide_slot_unused(w, e);
         f.lo_x[e] = empty ? inf : pt_grid_plane((w.q[0] >> (8 * e)) & 255u, w.scale_x, w.origin[0]);
         f.lo_y[e] = empty ? inf : pt_grid_plane((w.q[1] >> (8 * e)) & 255u, w.scale_y, w.origin[1]);
         f.lo_z[e] = empty ? inf : pt_grid_plane((w.q[2] >> (8 * e)) & 255u, w.scale_z, w.origin[2]);
@@ -452,6 +452,10 @@ __global__ void k_wide_expand(const PtWide4* __restrict__ in, uint32_t n, PtWide
 }
 
 // Copies wide nodes into a pool: inner references move by node_base, triangle positions by tri_base.
+// In the pool an unused slot is an inverted box (low bytes 255, high bytes 0: the far plane is never behind the
+// near one, so no ray interval overlaps it) whose reference repeats slot 0's.  The traversal step then needs no test
+// of the reference: should rounding ever collapse the six distances of such a slot into one value and let it
+// pass, the ray visits slot 0's child a second time, which changes no closest hit.
 __global__ void k_wide_rebase(const PtWide4* __restrict__ in, uint32_t n, uint32_t node_base, uint32_t tri_base, PtWide4* __restrict__ out)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -459,7 +463,11 @@ __global__ void k_wide_rebase(const PtWide4* __restrict__ in, uint32_t n, uint32
     PtWide4 w = in[i];
     for (int e = 0; e < 4; ++e) {
         const int32_t c = w.child[e];
-        if (c == PT_WIDE_EMPTY) continue;
+        if (c == PT_WIDE_EMPTY) {
+            w.child[e] = w.child[0];       // (already rebased; slot 0 is always in use)
+            for (int k = 0; k < 3; ++k) { w.q[k] |= 255u << (8 * e); w.q[3 + k] &= ~(255u << (8 * e)); }
+            continue;
+        }
         w.child[e] = c >= 0 ? (int32_t)((uint32_t)c + node_base) : pt_wide_leaf_rebased(c, tri_base);
     }
     out[node_base + i] = w;
@@ -1210,6 +1218,14 @@ int pt_tlas_wide_download(const PtTlas* t, void* nodes64, uint32_t capacity, uin
     PT_REQUIRE(capacity >= t->wide_count, "capacity is smaller than the number of wide nodes");
     PT_HIP_CHECK(hipSetDevice(t->ctx->device));
     PT_HIP_CHECK(hipMemcpy(nodes64, t->pool_nodes, sizeof(PtWide4) * (size_t)t->wide_count, hipMemcpyDeviceToHost));
+    // the pool marks unused slots its own way (k_wide_rebase); what is handed out is the builder's form
+    PtWide4* w = (PtWide4*)nodes64;
+    for (uint32_t i = 0; i < t->wide_count; ++i)
+        for (int e = 0; e < 4; ++e)
+            if (pt_wide_slot_unused(w[i], e)) {
+                w[i].child[e] = PT_WIDE_EMPTY;
+                for (int k = 0; k < 6; ++k) w[i].q[k] &= ~(255u << (8 * e));
+            }
     return PT_OK;
 }
 

@@ -324,7 +324,7 @@ __device__ __forceinline__ int pt_wide_step(const PtRaySpace& r, const float4* _
         const float by = PT_FMA(PT_FMA((float)((Fy >> (8 * k)) & 255u), sy, h0.y), r.iy, -r.ooy);
         const float bz = PT_FMA(PT_FMA((float)((Fz >> (8 * k)) & 255u), sz, h0.z), r.iz, -r.ooz);
         const float a = fmaxf(fmaxf(ax, ay), az), b = fminf(fminf(bx, by), bz);
-        const bool hit = (ref_in[k] != PT_NODE_EMPTY) && fmaxf(a, tlo) <= fminf(b, hi);
+        const bool hit = fmaxf(a, tlo) <= fminf(b, hi);      // an unused slot is an inverted box in the pool (k_wide_rebase): no test of the reference
         tn[k] = hit ? a : inf;
         ref[k] = ref_in[k];
     }
@@ -343,17 +343,11 @@ __device__ __forceinline__ int pt_wide_step(const PtRaySpace& r, const float4* _
                          const int ra = sw ? ref[j] : ref[i], rb = sw ? ref[i] : ref[j]; tn[i] = ta; tn[j] = tb; ref[i] = ra; ref[j] = rb; }
     PT_CSWAP(0, 1) PT_CSWAP(2, 3) PT_CSWAP(0, 2) PT_CSWAP(1, 3) PT_CSWAP(1, 2)
 #undef PT_CSWAP
-    if constexpr (!F32) {
-        // The children to go on with are the nh smallest keys, at the front.  (Quantised planes are finite, so the
-        // entry distances of a node are NaN for all of its children or for none: the order is total and the count
-        // taken before the network holds after it.  The float planes of an empty child are infinite and can mix
-        // NaNs in for a ray that is not finite, so that form counts again.)
-        stk.push_far_to_near(ref[1], ref[2], ref[3], max(nh - 1, 0));
-        return nh > 0 ? ref[0] : stk.pop();
-    }
-    const int m = (tn[1] < inf ? 1 : 0) + (tn[2] < inf ? 1 : 0) + (tn[3] < inf ? 1 : 0);
-    stk.push_far_to_near(ref[1], ref[2], ref[3], m);
-    return tn[0] < inf ? ref[0] : stk.pop();
+    // The children to go on with are the nh smallest keys, at the front: the count taken before the network holds
+    // after it.  (For a ray that is not finite some keys can be NaN and the order is then not total; every slot of a
+    // pool node holds a valid reference, so whatever such a ray goes on with, it reads no memory it should not.)
+    stk.push_far_to_near(ref[1], ref[2], ref[3], max(nh - 1, 0));
+    return nh > 0 ? ref[0] : stk.pop();
 }
 
 // Moves a world-space ray into the object space of an instance (world->object rows r0..r2).

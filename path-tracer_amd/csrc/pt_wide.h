@@ -42,6 +42,8 @@ static_assert(sizeof(PtWideF) == 128, "float wide node must be 128 bytes");
 #define PT_HD
 #endif
 #define PT_WIDE_EMPTY ((int32_t)0x80000000)
+// Slot e of a pool node is unused: its box is inverted (a child's low byte never exceeds its high byte).
+PT_HD static inline bool pt_wide_slot_unused(const PtWide4& w, int e) { return ((w.q[0] >> (8 * e)) & 255u) > ((w.q[3] >> (8 * e)) & 255u); }
 
 struct PtWideEntry { int32_t ref; float lo[3], hi[3]; };
 
