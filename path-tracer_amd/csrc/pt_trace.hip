@@ -359,6 +359,83 @@ __device__ __forceinline__ void shade_miss(uint32_t depth, const float4 cw, floa
     hv.x = PT_FMA(e, cw.x, hv.x); hv.y = PT_FMA(e, cw.y, hv.y); hv.z = PT_FMA(e, cw.z, hv.z);
 }
 
+// closest_hit.rchit:55-86 for one hit, followed by ray_gen.rgen:67: the next ray (origin o, direction d), the factor
+// w of the path weight, the seed after its two draws, and the emission times the path weight added to hv.
+__device__ __forceinline__ void pt_shade_hit(const PtDevShadeInstance* __restrict__ shade_inst, const PtHit h, uint32_t& seed_io,
+                                             const float4 cw, float4& hv, float4& no, float4& nd, float& wr_out, float& wg_out, float& wb_out)
+{
+    // closest_hit.rchit:57-60 (table chain pre-resolved per instance)
+    const PtDevShadeInstance& I = shade_inst[h.instance];
+    const float4 ptrs = I.ptrs;
+    // UnpackGeometry, closest_hit.rchit:33-53: the primitive's three vertices, gathered when the tables were bound
+    const float4* rec = (const float4*)ptr_from(ptrs.x, ptrs.y) + 6 * (size_t)h.primitive;
+    const float4 a0 = rec[0], a1 = rec[1], b0_ = rec[2], b1_ = rec[3], c0 = rec[4], c1 = rec[5];
+    const PtVertex A = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
+    const PtVertex B = { b0_.x, b0_.y, b0_.z, b0_.w, b1_.x, b1_.y, b1_.z, b1_.w };
+    const PtVertex C = { c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w };
+    const float b0 = 1.0f - h.u - h.v, b1 = h.u, b2 = h.v;
+#define PT_MIX3(x, y, z) PT_FMA((z), b2, PT_FMA((y), b1, (x) * b0))
+    float px = PT_MIX3(A.px, B.px, C.px), py = PT_MIX3(A.py, B.py, C.py), pz = PT_MIX3(A.pz, B.pz, C.pz);
+    float nx = PT_MIX3(A.nx, B.nx, C.nx), ny = PT_MIX3(A.ny, B.ny, C.ny), nz = PT_MIX3(A.nz, B.nz, C.nz);
+    float tu = PT_MIX3(A.tu, B.tu, C.tu), tv = PT_MIX3(A.tv, B.tv, C.tv);
+#undef PT_MIX3
+    pt_normalize(nx, ny, nz);
+    // :62-63
+    const float4 m0 = I.o2w[0], m1 = I.o2w[1], m2 = I.o2w[2];
+    float wx = PT_FMA(m0.x, px, PT_FMA(m0.y, py, PT_FMA(m0.z, pz, m0.w)));
+    float wy = PT_FMA(m1.x, px, PT_FMA(m1.y, py, PT_FMA(m1.z, pz, m1.w)));
+    float wz = PT_FMA(m2.x, px, PT_FMA(m2.y, py, PT_FMA(m2.z, pz, m2.w)));
+    const float4 w0 = I.w2o[0], w1 = I.w2o[1], w2 = I.w2o[2];
+    float Nx = PT_FMA(w0.x, nx, PT_FMA(w1.x, ny, w2.x * nz));
+    float Ny = PT_FMA(w0.y, nx, PT_FMA(w1.y, ny, w2.y * nz));
+    float Nz = PT_FMA(w0.z, nx, PT_FMA(w1.z, ny, w2.z * nz));
+    pt_normalize(Nx, Ny, Nz);
+    // CreateCoordinateSystem, sampling.glsl:53-65
+    float Tx, Ty, Tz;
+    if (fabsf(Nx) > fabsf(Ny)) {
+        float inv = pt_rcp(pt_sqrt(PT_FMA(Nz, Nz, Nx * Nx)));
+        Tx = Nz * inv; Ty = 0.0f; Tz = -Nx * inv;
+    } else {
+        float inv = pt_rcp(pt_sqrt(PT_FMA(Nz, Nz, Ny * Ny)));
+        Tx = 0.0f; Ty = -Nz * inv; Tz = Ny * inv;
+    }
+    float Bx = PT_FMA(Ny, Tz, -(Nz * Ty));
+    float By = PT_FMA(Nz, Tx, -(Nx * Tz));
+    float Bz = PT_FMA(Nx, Ty, -(Ny * Tx));
+    // SamplingHemisphere, sampling.glsl:38-50
+    uint32_t seed = seed_io;
+    float r1 = pt_random(seed);
+    float r2 = pt_random(seed);
+    float sq = pt_sqrt(r1);
+    float sn, cs;
+    pt_sincos(6.28318548f * r2, sn, cs);
+    float lx = cs * sq, ly = sn * sq, lz = pt_sqrt(1.0f - r1);
+    float Dx = PT_FMA(lz, Nx, PT_FMA(ly, Bx, lx * Tx));
+    float Dy = PT_FMA(lz, Ny, PT_FMA(ly, By, lx * Ty));
+    float Dz = PT_FMA(lz, Nz, PT_FMA(ly, Bz, lx * Tz));
+    // :71-85
+    float cosTheta = PT_FMA(Dz, Nz, PT_FMA(Dy, Ny, Dx * Nx));
+    float pdf = pt_div_pi(cosTheta);
+    const float4 alb = I.albedo;
+    float ar = alb.x, ag = alb.y, ab = alb.z;
+    if (__float_as_uint(alb.w)) {
+        const float4 tex = I.tex;
+        float tr, tg, tbb;
+        pt_texture_rgb((const uint32_t*)ptr_from(tex.x, tex.y), (int)__float_as_uint(tex.z), (int)__float_as_uint(tex.w), tu, tv, tr, tg, tbb);
+        ar = ar * tr; ag = ag * tg; ab = ab * tbb;
+    }
+    float wr = pt_div_pi(ar) * cosTheta / pdf, wg = pt_div_pi(ag) * cosTheta / pdf, wb = pt_div_pi(ab) * cosTheta / pdf;
+    // ray_gen.rgen:67-68
+    const float4 em = I.emissive;
+    hv.x = PT_FMA(em.x, cw.x, hv.x);
+    hv.y = PT_FMA(em.y, cw.y, hv.y);
+    hv.z = PT_FMA(em.z, cw.z, hv.z);
+    no = make_float4(wx, wy, wz, 0.0f);
+    nd = make_float4(Dx, Dy, Dz, 0.0f);
+    wr_out = wr; wg_out = wg; wb_out = wb;
+    seed_io = seed;
+}
+
 // Shades the 64 slots of one batch (slot i per lane, hit h) and compacts the surviving paths into the
 // same shard of the next queue.  Called by every lane of the wave, valid or not.
 // FIRST: bounce 0, where the path weight is 1 and the collected radiance 0 and neither is read.
@@ -390,75 +467,11 @@ __device__ __forceinline__ void shade_batch(const PtShadeArgs& S, const PtDevSha
             path_result[path] = hv;
         } else {
             if (FIRST) { uint32_t slot_unused; pt_primary_seed(S.primary, path, seed_in, slot_unused); }
-            // closest_hit.rchit:57-60 (table chain pre-resolved per instance)
-            const PtDevShadeInstance& I = shade_inst[h.instance];
-            const float4 ptrs = I.ptrs;
-            // UnpackGeometry, closest_hit.rchit:33-53: the primitive's three vertices, gathered when the tables were bound
-            const float4* rec = (const float4*)ptr_from(ptrs.x, ptrs.y) + 6 * (size_t)h.primitive;
-            const float4 a0 = rec[0], a1 = rec[1], b0_ = rec[2], b1_ = rec[3], c0 = rec[4], c1 = rec[5];
-            const PtVertex A = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
-            const PtVertex B = { b0_.x, b0_.y, b0_.z, b0_.w, b1_.x, b1_.y, b1_.z, b1_.w };
-            const PtVertex C = { c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w };
-            const float b0 = 1.0f - h.u - h.v, b1 = h.u, b2 = h.v;
-#define PT_MIX3(x, y, z) PT_FMA((z), b2, PT_FMA((y), b1, (x) * b0))
-            float px = PT_MIX3(A.px, B.px, C.px), py = PT_MIX3(A.py, B.py, C.py), pz = PT_MIX3(A.pz, B.pz, C.pz);
-            float nx = PT_MIX3(A.nx, B.nx, C.nx), ny = PT_MIX3(A.ny, B.ny, C.ny), nz = PT_MIX3(A.nz, B.nz, C.nz);
-            float tu = PT_MIX3(A.tu, B.tu, C.tu), tv = PT_MIX3(A.tv, B.tv, C.tv);
-#undef PT_MIX3
-            pt_normalize(nx, ny, nz);
-            // :62-63
-            const float4 m0 = I.o2w[0], m1 = I.o2w[1], m2 = I.o2w[2];
-            float wx = PT_FMA(m0.x, px, PT_FMA(m0.y, py, PT_FMA(m0.z, pz, m0.w)));
-            float wy = PT_FMA(m1.x, px, PT_FMA(m1.y, py, PT_FMA(m1.z, pz, m1.w)));
-            float wz = PT_FMA(m2.x, px, PT_FMA(m2.y, py, PT_FMA(m2.z, pz, m2.w)));
-            const float4 w0 = I.w2o[0], w1 = I.w2o[1], w2 = I.w2o[2];
-            float Nx = PT_FMA(w0.x, nx, PT_FMA(w1.x, ny, w2.x * nz));
-            float Ny = PT_FMA(w0.y, nx, PT_FMA(w1.y, ny, w2.y * nz));
-            float Nz = PT_FMA(w0.z, nx, PT_FMA(w1.z, ny, w2.z * nz));
-            pt_normalize(Nx, Ny, Nz);
-            // CreateCoordinateSystem, sampling.glsl:53-65
-            float Tx, Ty, Tz;
-            if (fabsf(Nx) > fabsf(Ny)) {
-                float inv = pt_rcp(pt_sqrt(PT_FMA(Nz, Nz, Nx * Nx)));
-                Tx = Nz * inv; Ty = 0.0f; Tz = -Nx * inv;
-            } else {
-                float inv = pt_rcp(pt_sqrt(PT_FMA(Nz, Nz, Ny * Ny)));
-                Tx = 0.0f; Ty = -Nz * inv; Tz = Ny * inv;
-            }
-            float Bx = PT_FMA(Ny, Tz, -(Nz * Ty));
-            float By = PT_FMA(Nz, Tx, -(Nx * Tz));
-            float Bz = PT_FMA(Nx, Ty, -(Ny * Tx));
-            // SamplingHemisphere, sampling.glsl:38-50
-            uint32_t seed = seed_in;
-            float r1 = pt_random(seed);
-            float r2 = pt_random(seed);
-            float sq = pt_sqrt(r1);
-            float sn, cs;
-            pt_sincos(6.28318548f * r2, sn, cs);
-            float lx = cs * sq, ly = sn * sq, lz = pt_sqrt(1.0f - r1);
-            float Dx = PT_FMA(lz, Nx, PT_FMA(ly, Bx, lx * Tx));
-            float Dy = PT_FMA(lz, Ny, PT_FMA(ly, By, lx * Ty));
-            float Dz = PT_FMA(lz, Nz, PT_FMA(ly, Bz, lx * Tz));
-            // :71-85
-            float cosTheta = PT_FMA(Dz, Nz, PT_FMA(Dy, Ny, Dx * Nx));
-            float pdf = pt_div_pi(cosTheta);
-            const float4 alb = I.albedo;
-            float ar = alb.x, ag = alb.y, ab = alb.z;
-            if (__float_as_uint(alb.w)) {
-                const float4 tex = I.tex;
-                float tr, tg, tbb;
-                pt_texture_rgb((const uint32_t*)ptr_from(tex.x, tex.y), (int)__float_as_uint(tex.z), (int)__float_as_uint(tex.w), tu, tv, tr, tg, tbb);
-                ar = ar * tr; ag = ag * tg; ab = ab * tbb;
-            }
-            float wr = pt_div_pi(ar) * cosTheta / pdf, wg = pt_div_pi(ag) * cosTheta / pdf, wb = pt_div_pi(ab) * cosTheta / pdf;
-            // ray_gen.rgen:67-68
-            const float4 em = I.emissive;
-            hv.x = PT_FMA(em.x, cw.x, hv.x);
-            hv.y = PT_FMA(em.y, cw.y, hv.y);
-            hv.z = PT_FMA(em.z, cw.z, hv.z);
+            float4 po, pd; float wr, wg, wb; uint32_t seed = seed_in;
+            pt_shade_hit(shade_inst, h, seed, cw, hv, po, pd, wr, wg, wb);
             if (alive) {
-                no = make_float4(wx, wy, wz, 0.0f);
-                nd = make_float4(Dx, Dy, Dz, 0.0f);
+                no = po;
+                nd = pd;
                 nw = make_float4(cw.x * wr, cw.y * wg, cw.z * wb, __uint_as_float(seed));
                 nh = make_float4(hv.x, hv.y, hv.z, __uint_as_float(path));
             } else {

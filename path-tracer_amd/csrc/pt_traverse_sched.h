@@ -115,6 +115,17 @@ __device__ __forceinline__ void pt_traverse_sched(const PtTlasView& tl, const Pt
     // finish one or two lanes at a time, and a record written where the ray ends costs the whole wave
     // a pass per ray (10 % of the kernel); written here, one pass serves every lane that waits.
     PT_COLD(4) = -1;               // queue slot of the ray whose record is still to be written, or -1 (a flag in a register was measured 1 % slower)
+    // Hands the lane the ray of queue slot `tag`.
+    auto start_ray = [&](const float4 o, const float4 d, int tag) {
+        PT_COLD(4) = tag; PT_COLD(0) = (int)PT_NO_INSTANCE; PT_COLD(1) = -1; PT_COLD(2) = 0; PT_COLD(3) = 0;
+        pt_ray_space_init(cur, o.x, o.y, o.z, d.x, d.y, d.z);
+        ws[0 * PT_TRAVERSE_BLOCK] = cur.ox; ws[1 * PT_TRAVERSE_BLOCK] = cur.oy; ws[2 * PT_TRAVERSE_BLOCK] = cur.oz;
+        ws[3 * PT_TRAVERSE_BLOCK] = cur.dx; ws[4 * PT_TRAVERSE_BLOCK] = cur.dy; ws[5 * PT_TRAVERSE_BLOCK] = cur.dz;
+        ws[6 * PT_TRAVERSE_BLOCK] = cur.ix; ws[7 * PT_TRAVERSE_BLOCK] = cur.iy; ws[8 * PT_TRAVERSE_BLOCK] = cur.iz;
+        cur_inst = PT_NO_INSTANCE; tlo = tmin; thi = tmax;
+        best_t = tmax;
+        node = pt_ray_start(tl, stk);
+    };
     auto flush = [&]() {
         if (node == PT_NODE_DONE && PT_COLD(4) != -1) {
             const uint32_t qi = (uint32_t)PT_COLD(4);
@@ -129,8 +140,9 @@ __device__ __forceinline__ void pt_traverse_sched(const PtTlasView& tl, const Pt
     for (;;) {
         // ------------------------------------------------------------------ refill idle lanes
         unsigned long long idle = __ballot(node == PT_NODE_DONE);
-        if (idle == ~0ull || __popcll(idle) >= PT_SCHED_REFILL) flush();
-        if (!drained && (idle == ~0ull || __popcll(idle) >= PT_SCHED_REFILL)) {
+        const bool refill = idle == ~0ull || __popcll(idle) >= PT_SCHED_REFILL;
+        if (refill) flush();
+        if (!drained && refill) {
             while (idle) {
                 PT_STAT(7, 1);
                 if (wcur == wend) {
@@ -160,15 +172,8 @@ __device__ __forceinline__ void pt_traverse_sched(const PtTlasView& tl, const Pt
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));   // set bits of idle below this lane
                 if (node == PT_NODE_DONE && rank < take) {
                     const uint32_t slot = wcur + rank;
-                    PT_COLD(4) = (int)slot; PT_COLD(0) = (int)PT_NO_INSTANCE; PT_COLD(1) = -1; PT_COLD(2) = 0; PT_COLD(3) = 0;
                     const float4 o = pt_stream_load(&q0[slot]), d = pt_stream_load(&q1[slot]);
-                    pt_ray_space_init(cur, o.x, o.y, o.z, d.x, d.y, d.z);
-                    ws[0 * PT_TRAVERSE_BLOCK] = cur.ox; ws[1 * PT_TRAVERSE_BLOCK] = cur.oy; ws[2 * PT_TRAVERSE_BLOCK] = cur.oz;
-                    ws[3 * PT_TRAVERSE_BLOCK] = cur.dx; ws[4 * PT_TRAVERSE_BLOCK] = cur.dy; ws[5 * PT_TRAVERSE_BLOCK] = cur.dz;
-                    ws[6 * PT_TRAVERSE_BLOCK] = cur.ix; ws[7 * PT_TRAVERSE_BLOCK] = cur.iy; ws[8 * PT_TRAVERSE_BLOCK] = cur.iz;
-                    cur_inst = PT_NO_INSTANCE; tlo = tmin; thi = tmax;
-                    best_t = tmax;
-                    node = pt_ray_start(tl, stk);
+                    start_ray(o, d, (int)slot);
                 }
                 wcur += take;
                 idle = __ballot(node == PT_NODE_DONE);
