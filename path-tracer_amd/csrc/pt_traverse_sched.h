@@ -101,15 +101,11 @@ __device__ __forceinline__ void pt_traverse_sched(const PtTlasView& tl, const Pt
     stk.sp = 0;
     cur.ox = cur.oy = cur.oz = cur.dx = cur.dy = cur.dz = cur.ix = cur.iy = cur.iz = cur.oox = cur.ooy = cur.ooz = 0.0f;
 
-    // Takes the next item for this lane after the current one is exhausted: pops until an inner node,
-    // a leaf, the end of an instance's BLAS (with something left above it) or the end of the ray comes up.
-    auto advance = [&](int v) {
-        // Leaving an instance with nothing left above it: the ray is finished, its world-space form is not
-        // needed.  Otherwise the sentinel stays the lane's item: a few lanes at a time get here and the whole
-        // wave would pay for what they do, so the lane waits for the instance phase, which takes it back to
-        // world space together with the lanes that enter or leave an instance then.
-        node = (v == PT_NODE_SENTINEL && stk.sp == 0) ? PT_NODE_DONE : v;
-    };
+    // A lane that has come to the end of an instance's BLAS pops the sentinel pushed when it entered and keeps it as
+    // its item: a few lanes at a time get there and the whole wave would pay for what they do, so the lane waits for
+    // the instance phase, which takes it back to world space together with the lanes that enter or leave an
+    // instance then.  An instance entered with nothing else on the stack pushes no sentinel: when its BLAS is
+    // exhausted the ray is finished (the pop says so) and its world-space form is not needed again.
 
     // A finished ray keeps its closest hit in `cold` until its lane is refilled (or the wave ends): rays
     // finish one or two lanes at a time, and a record written where the ray ends costs the whole wave
@@ -202,8 +198,7 @@ __device__ __forceinline__ void pt_traverse_sched(const PtTlasView& tl, const Pt
             do {
                 { const int act_ = __popcll(__ballot(want_node)); (void)act_; PT_STAT(0, 1); PT_STAT(3, act_); }
                 if (want_node) {
-                    const int next = pt_wide_step<false>(cur, tl.nodes, node, tlo, fminf(thi, best_t), stk);
-                    if ((unsigned)next < (unsigned)PT_NODE_DONE) node = next; else advance(next);
+                    node = pt_wide_step<false>(cur, tl.nodes, node, tlo, fminf(thi, best_t), stk);
                     want_node = (unsigned)node < (unsigned)PT_NODE_DONE;
                 }
                 n_node = __popcll(__ballot(want_node));
@@ -233,7 +228,7 @@ __device__ __forceinline__ void pt_traverse_sched(const PtTlasView& tl, const Pt
                     }
                     // one triangle per step: first + 1, count - 1
                     if (code & 7u) node = (int)~(code + 7u);
-                    else advance(stk.pop());
+                    else node = stk.pop();
                     want_leaf = node < 0 && cur_inst != PT_NO_INSTANCE;
                 }
                 n_leaf = __popcll(__ballot(want_leaf));
@@ -264,11 +259,11 @@ __device__ __forceinline__ void pt_traverse_sched(const PtTlasView& tl, const Pt
                         PT_COLD(5) = __float_as_int(blo.w);
                         cur_inst = __float_as_uint(misc.y);
                         tlo = fmaxf(tmin, a); thi = fminf(tmax, b);
-                        stk.push(PT_NODE_SENTINEL);
+                        if (stk.sp > 0) stk.push(PT_NODE_SENTINEL);
                         node = __float_as_int(misc.x);
                     }
                 }
-                if (!enter) advance(stk.pop());
+                if (!enter) node = stk.pop();
             }
         }
     }
