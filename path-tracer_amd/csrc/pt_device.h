@@ -116,26 +116,33 @@ __device__ __forceinline__ void pt_slab(const PtRaySpace& r, float lox, float lo
 
 __device__ __forceinline__ float pt_sel3(int k, float x, float y, float z) { return k == 0 ? x : (k == 1 ? y : z); }
 
-// Gated watertight ray/triangle test (Woop, Benthin, Wald 2013).  The axis permutation and shear are
-// recomputed from the ray on every call instead of being carried in registers: kz = dominant axis
-// (lowest index on ties), Sz = 1/d[kz] (the slab test's reciprocal), Sx = d[kx]*Sz, Sy = d[ky]*Sz.
-// Returns true when the edge functions agree in sign, det != 0 and t lies inside the slab interval of
-// the triangle's own box padded by delta.
-__device__ __forceinline__ bool pt_tri_test(const PtRaySpace& r, float delta,
-                                            float v0x, float v0y, float v0z, float v1x, float v1y, float v1z,
-                                            float v2x, float v2y, float v2z, float& t, float& u, float& v)
+// Gated watertight ray/triangle test (Woop, Benthin, Wald 2013).  The part that depends on the ray alone:
+// kz = dominant axis (lowest index on ties), kx and ky the two others in cyclic order, exchanged when d[kz] < 0,
+// Sz = 1/d[kz] (the slab test's reciprocal), Sx = d[kx]*Sz, Sy = d[ky]*Sz.
+struct PtTriSetup { int kx, ky, kz; float Sx, Sy, Sz; };
+__device__ __forceinline__ PtTriSetup pt_tri_setup(float dx, float dy, float dz, float ix, float iy, float iz)
 {
-    int kz = 0;
-    float m = fabsf(r.dx);
-    if (fabsf(r.dy) > m) { kz = 1; m = fabsf(r.dy); }
-    if (fabsf(r.dz) > m) { kz = 2; }
-    int kx = kz == 2 ? 0 : kz + 1;
-    int ky = kx == 2 ? 0 : kx + 1;
-    if (pt_sel3(kz, r.dx, r.dy, r.dz) < 0.0f) { int s = kx; kx = ky; ky = s; }
-    const float Sz = pt_sel3(kz, r.ix, r.iy, r.iz);
-    const float Sx = pt_sel3(kx, r.dx, r.dy, r.dz) * Sz;
-    const float Sy = pt_sel3(ky, r.dx, r.dy, r.dz) * Sz;
-
+    PtTriSetup s;
+    s.kz = 0;
+    float m = fabsf(dx);
+    if (fabsf(dy) > m) { s.kz = 1; m = fabsf(dy); }
+    if (fabsf(dz) > m) { s.kz = 2; }
+    s.kx = s.kz == 2 ? 0 : s.kz + 1;
+    s.ky = s.kx == 2 ? 0 : s.kx + 1;
+    if (pt_sel3(s.kz, dx, dy, dz) < 0.0f) { int t = s.kx; s.kx = s.ky; s.ky = t; }
+    s.Sz = pt_sel3(s.kz, ix, iy, iz);
+    s.Sx = pt_sel3(s.kx, dx, dy, dz) * s.Sz;
+    s.Sy = pt_sel3(s.ky, dx, dy, dz) * s.Sz;
+    return s;
+}
+// The test itself, for a ray with origin (ox, oy, oz) whose slab terms are in r.  Returns true when the edge
+// functions agree in sign, det != 0 and t lies inside the slab interval of the triangle's own box padded by delta.
+__device__ __forceinline__ bool pt_tri_test_with(const PtTriSetup& S, const PtRaySpace& r, float delta,
+                                                 float v0x, float v0y, float v0z, float v1x, float v1y, float v1z,
+                                                 float v2x, float v2y, float v2z, float& t, float& u, float& v)
+{
+    const int kx = S.kx, ky = S.ky, kz = S.kz;
+    const float Sx = S.Sx, Sy = S.Sy, Sz = S.Sz;
     float Ax_ = v0x - r.ox, Ay_ = v0y - r.oy, Az_ = v0z - r.oz;
     float Bx_ = v1x - r.ox, By_ = v1y - r.oy, Bz_ = v1z - r.oz;
     float Cx_ = v2x - r.ox, Cy_ = v2y - r.oy, Cz_ = v2z - r.oz;
@@ -157,6 +164,13 @@ __device__ __forceinline__ bool pt_tri_test(const PtRaySpace& r, float delta,
     pt_slab(r, fminf(fminf(v0x, v1x), v2x) - delta, fminf(fminf(v0y, v1y), v2y) - delta, fminf(fminf(v0z, v1z), v2z) - delta,
             fmaxf(fmaxf(v0x, v1x), v2x) + delta, fmaxf(fmaxf(v0y, v1y), v2y) + delta, fmaxf(fmaxf(v0z, v1z), v2z) + delta, tn, tf);
     return t >= tn && t <= tf;
+}
+// The form that works the ray's part out on every call (where a lane's registers cannot hold it between calls).
+__device__ __forceinline__ bool pt_tri_test(const PtRaySpace& r, float delta,
+                                            float v0x, float v0y, float v0z, float v1x, float v1y, float v1z,
+                                            float v2x, float v2y, float v2z, float& t, float& u, float& v)
+{
+    return pt_tri_test_with(pt_tri_setup(r.dx, r.dy, r.dz, r.ix, r.iy, r.iz), r, delta, v0x, v0y, v0z, v1x, v1y, v1z, v2x, v2y, v2z, t, u, v);
 }
 
 struct PtHitRec { float t; uint32_t inst, prim; float u, v; };

@@ -213,7 +213,13 @@ __device__ __forceinline__ void pt_traverse_sched(const PtTlasView& tl, const Pt
                     const float4 a = tl.tris[3 * (size_t)pos + 0], b = tl.tris[3 * (size_t)pos + 1], c = tl.tris[3 * (size_t)pos + 2];
                     const float delta = __int_as_float(PT_COLD(5));
                     float t, u, v;
-                    if (pt_tri_test(cur, delta, a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, t, u, v)) {
+                    // inside an instance the direction's registers hold the triangle test's shear and axes (set on entry)
+                    PtTriSetup S;
+                    S.Sx = cur.dx; S.Sy = cur.dy;
+                    const uint32_t kk = __float_as_uint(cur.dz);
+                    S.kz = (int)(kk & 3u); S.kx = (int)((kk >> 2) & 3u); S.ky = (int)(kk >> 4);
+                    S.Sz = pt_sel3(S.kz, cur.ix, cur.iy, cur.iz);
+                    if (pt_tri_test_with(S, cur, delta, a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, t, u, v)) {
                         const uint32_t prim = __float_as_uint(c.y);
                         if (t > tmin && t < tmax && t >= tlo && t <= thi) {
                             // the order of pt_hit_update; the ids are only looked at on an exact tie
@@ -256,6 +262,11 @@ __device__ __forceinline__ void pt_traverse_sched(const PtTlasView& tl, const Pt
                     enter = pt_ray_valid(odx, ody, odz);
                     if (enter) {
                         pt_ray_space_init(cur, oox, ooy, ooz, odx, ody, odz);
+                        // The box steps inside the instance read the reciprocals only, and the direction comes back
+                        // from LDS when the lane leaves: until then its three registers carry what the triangle
+                        // test derives from the ray alone, worked out once per entry instead of once per test.
+                        const PtTriSetup S = pt_tri_setup(odx, ody, odz, cur.ix, cur.iy, cur.iz);
+                        cur.dx = S.Sx; cur.dy = S.Sy; cur.dz = __uint_as_float((uint32_t)S.kz | ((uint32_t)S.kx << 2) | ((uint32_t)S.ky << 4));
                         PT_COLD(5) = __float_as_int(blo.w);
                         cur_inst = __float_as_uint(misc.y);
                         tlo = fmaxf(tmin, a); thi = fminf(tmax, b);
