@@ -5,7 +5,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-prefix = sys.argv[1] if len(sys.argv) > 1 else "r03_v2"
+prefix = sys.argv[1] if len(sys.argv) > 1 else "r03_v4"
 
 
 def line(name):
