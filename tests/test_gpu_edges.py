@@ -78,6 +78,40 @@ def test_degenerate_rays(cube, schedule, monkeypatch):
 
 
 @pytest.mark.parametrize("schedule", ["plain", "sched"])
+def test_direction_lengths_beyond_the_short_reciprocal(cube, dragon, schedule, monkeypatch):
+    """The kernels take 1/x by the hardware approximation and one correction while every operand of the wave lies in
+    2^-100 .. 2^100, and by the IEEE division otherwise.  Directions of length 2^105, 2^120 and 2^-95 (whose
+    components fall below the 2^-80 clamp of the slab reciprocal) mixed into waves of ordinary rays take both
+    forms, with an interval wide enough for their hit distances: ids, distances and barycentrics as the oracle's."""
+    import oracle as O
+    from pt_amd import hip
+    monkeypatch.setenv("PT_HIP_TRAVERSAL", schedule)
+    rng = np.random.default_rng(41)
+    for scene, ext in ((cube, 2.0), (dragon, 1.5)):
+        n = 6000
+        o = rng.uniform(-ext, ext, size=(n, 3)).astype(np.float32)
+        o[:, 1] += 1.0 if scene is dragon else 0.0
+        tgt = rng.uniform(-0.5, 0.5, size=(n, 3)).astype(np.float32)
+        tgt[:, 1] += 0.6 if scene is dragon else 0.0
+        d = tgt - o
+        d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+        k = np.arange(n)
+        d[k % 7 == 1] *= np.float32(2.0 ** 105)
+        d[k % 11 == 2] *= np.float32(2.0 ** -95)
+        d[(k % 13 == 3) & (k % 7 != 1)] *= np.float32(2.0 ** 120)
+        orc = O.OracleScene(scene)
+        r = hip.Renderer(scene, 8, 8)
+        try:
+            hg, tg = r.intersect(o, d, tmin=1e-37, tmax=3e38)
+            ho, to = orc.tlas.intersect(o, d, tmin=1e-37, tmax=3e38)
+        finally:
+            r.close()
+        assert np.array_equal(hg, ho) and _float_eq(tg, to)
+        scaled = (k % 7 == 1) | (k % 11 == 2) | (k % 13 == 3)
+        assert (ho["instance"][scaled] != 0xFFFFFFFF).sum() > 100 and (ho["instance"][~scaled] != 0xFFFFFFFF).sum() > 100
+
+
+@pytest.mark.parametrize("schedule", ["plain", "sched"])
 def test_single_triangle_and_degenerate_triangles(schedule, monkeypatch):
     """A one-triangle BLAS (no inner node), then a mesh mixing proper, zero-area and repeated
     triangles (all keys equal, ties in the radix tree), instanced three times with scale and shear."""
